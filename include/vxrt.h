@@ -1,0 +1,169 @@
+/*
+ * vxrt.h -- C ABI of the MI355X-native voxel brickmap ray tracer (libvxrt.so).
+ *
+ * Drop-in boundary for the VoxelRT hot path of JoshuaLim007/VoxelEngine.  The
+ * reference exposes this path as C++ (namespace GPUDDA); each entry point below
+ * names the reference interface it replaces (paths relative to the reference
+ * checkout).  A C++ facade with the reference's own names and signatures sits on
+ * top of this ABI in include/GPUDDA/ (see INTEGRATION.md).
+ *
+ * Conventions: every call returns 0 on success or a negative vxrt_status; no
+ * exceptions, no exit().  Pointers named d_* are device (HIP) pointers, all
+ * others are host pointers.  `stream` is a hipStream_t passed as void* (NULL =
+ * HIP's null stream, as in the HIP API).  A context belongs to one device; calls on one
+ * context must be serialised by the caller.
+ */
+#ifndef VXRT_H
+#define VXRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VXRT_ABI_VERSION 1
+#define VXRT_EMPTY_SLOT 0xFFFFFFFFu
+#define VXRT_MAX_STEPS 2048 /* MAX_STEPS, VoxelRT/VolumeRaytracer.cuh:235 */
+
+typedef enum vxrt_status {
+    VXRT_OK = 0,
+    VXRT_ERR_INVALID = -1,   /* bad argument / unsupported shape */
+    VXRT_ERR_HIP = -2,       /* a HIP runtime call failed (see vxrt_last_error) */
+    VXRT_ERR_NO_WORLD = -3,  /* render/trace before a world was uploaded or built */
+    VXRT_ERR_NOMEM = -4
+} vxrt_status;
+
+typedef struct vxrt_ctx vxrt_ctx;
+
+/* ---- lifetime.  Replaces `new GPUDDA::VoxelRaytracer3D(count)` / `delete`
+ * (VoxelRT/VolumeRaytracer.cuh:318-334, VoxelApp/main.cu:41,197). */
+int vxrt_abi_version(void);
+int vxrt_create(int device, vxrt_ctx **out);
+int vxrt_destroy(vxrt_ctx *ctx);
+/* message of the last failing call on this thread (never NULL) */
+const char *vxrt_last_error(void);
+int vxrt_synchronize(vxrt_ctx *ctx);
+
+/* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,
+ * ::UploadVoxelBufferDatas, ::UploadVoxelBufferDataBounds and ::SetFactor
+ * (VoxelRT/VolumeRaytracer.cu:527-572, VolumeRaytracer.cuh:349).  The three
+ * reference tables are handed over as flat host arrays and copied into HBM:
+ *   coarse_bits : one bit per brick cell, tiled-linear order of GetSampleIndex
+ *                 (VolumeRaytracer.cuh:107-131), (ncells+31)/32 words
+ *   brick_slot  : per cell, index of the brick in `pool` or VXRT_EMPTY_SLOT
+ *                 (reference: a VoxelBuffer3D descriptor with its own allocation)
+ *   bounds      : per cell 6 floats {min xyz, max xyz}, brick-local inclusive voxel
+ *                 extents, empty = {0,0,0,-1,-1,-1} (layout of Bounds3Df)
+ *   pool        : nslots bricks of factor^3 bits each, tiled-linear inside the brick */
+typedef struct vxrt_world_desc {
+    uint32_t struct_size;
+    int32_t factor;       /* brick edge: 8, 16 or 32 */
+    int32_t cdims[3];     /* coarse cells per axis, each a multiple of 8 */
+    uint64_t nslots;
+    const uint32_t *coarse_bits;
+    const uint32_t *brick_slot;
+    const float *bounds;
+    const uint32_t *pool;
+} vxrt_world_desc;
+int vxrt_upload_world(vxrt_ctx *ctx, const vxrt_world_desc *desc);
+
+/* ---- on-device world construction.  Replaces CreateVoxels + PopulateVoxels
+ * (VoxelRT/VoxelWorldBuilder.cuh:12-32, .cu:10-35) followed by
+ * GenerateLowresVoxelBuffer (VoxelRT/VolumeRaytracer.cuh:379-516), without the
+ * dense intermediate: one workgroup per brick evaluates the generator, packs the
+ * brick, reduces its extents and sets the coarse bit. */
+typedef enum vxrt_generator {
+    VXRT_GEN_HASH_HEIGHTFIELD = 0, /* integer-only columns */
+    VXRT_GEN_PERLIN_REF = 1,       /* PopulateVoxels' 32-octave Perlin fBm terrain */
+    VXRT_GEN_INT_TERRAIN = 2       /* integer-only smooth terrain */
+} vxrt_generator;
+int vxrt_build_world_procedural(vxrt_ctx *ctx, int generator, int X, int Y, int Z, int factor);
+
+typedef struct vxrt_world_info {
+    int32_t factor;
+    int32_t cdims[3];
+    uint64_t ncells;
+    uint64_t nslots;
+    uint64_t hbm_bytes; /* bytes resident for the world tables */
+} vxrt_world_info;
+int vxrt_world_info_get(vxrt_ctx *ctx, vxrt_world_info *out);
+/* copy the resident world back in vxrt_world_desc layout; the caller provides host
+ * arrays sized from vxrt_world_info_get (pool may be NULL to skip it). */
+int vxrt_download_world(vxrt_ctx *ctx, uint32_t *coarse_bits, uint32_t *brick_slot, float *bounds,
+                        uint32_t *pool);
+
+/* ---- camera / lighting state.  Replaces Graphics::SetEnvironment, ::SetFOV,
+ * ::SetOrthoWindowSize, ::GetDirections (VoxelRT/Renderer.cu:27-42,278-303). */
+int vxrt_set_environment(vxrt_ctx *ctx, const float light_dir[3], const float light_color[3],
+                         const float ambient[3]);
+int vxrt_set_fov(vxrt_ctx *ctx, float fov_degrees);
+int vxrt_set_ortho_window_size(vxrt_ctx *ctx, float size_x, float size_y);
+void vxrt_get_directions(const float euler[3], float fwd[3], float up[3], float right[3]);
+
+/* ---- per-frame render.  Replaces Graphics::RenderScreen + kernel screenDispatch
+ * (VoxelRT/Renderer.cu:179-328).  The compile-time switches of the reference are
+ * run-time flags here. */
+typedef enum vxrt_mode { VXRT_MODE_SHADED = 0, VXRT_MODE_DEBUG = 1 } vxrt_mode;
+
+typedef struct vxrt_frame_stats {
+    uint64_t primary_rays, shadow_rays, bounce_rays, primary_hits;
+    uint64_t coarse_probes; /* Nc: in-range coarse cell probes */
+    uint64_t brick_entries; /* Nb */
+    uint64_t fine_probes;   /* Nf: in-range brick cell probes */
+} vxrt_frame_stats;
+
+typedef struct vxrt_render_flags {
+    uint32_t struct_size;
+    int32_t mode;            /* vxrt_mode; DEBUG = `#define DEBUG_VIEW` (Renderer.cu:4) */
+    int32_t checkerboard;    /* ENABLE_CHECKERBOARD_RENDER (Renderer.cu:5) */
+    int32_t shadow;          /* 1 = shadow ray of Renderer.cu:97-102 enabled */
+    int32_t bounce_samples;  /* `samples` of Renderer.cu:123 */
+    int32_t bounce_all_hits; /* 0 = reference gate `lDot == 0` (Renderer.cu:121); 1 = every hit pixel */
+    int32_t ortho;           /* `#define ORTHO` (Renderer.cuh:13) */
+    int64_t frame_number;    /* >= 0: value the kernel sees as FrameNumber; < 0: the context's own
+                                counter with the reference's post-copy increment (Renderer.cu:310,322) */
+    /* multi-GPU strip sharding: rows are cut into strips of `strip_rows`; strip s belongs to
+     * shard s % strip_count.  strip_count <= 1 renders the whole frame. */
+    int32_t strip_rows, strip_count, strip_index;
+    int32_t compact;         /* 1: d_fb (and AOVs) hold only this shard's strips, packed in order */
+    int32_t collect_stats;   /* 1: also count probes (slower kernel variant); rays are always counted */
+    float *d_color_aov;      /* optional W*H*3 float colour handed to the pixel store, or NULL */
+    int64_t *d_hit_aov;      /* optional W*H primary hit voxel index (x + X*(y + Y*z)) or -1, or NULL */
+    void *stream;
+} vxrt_render_flags;
+
+void vxrt_render_flags_default(vxrt_render_flags *flags);
+/* d_fb: device BGRA8 framebuffer (bytes b,g,r,a = SDLRenderer.h:8-11 PixelData), W*H*4 bytes
+ * (or the compact size, see vxrt_compact_rows).  Asynchronous on the stream. */
+int vxrt_render(vxrt_ctx *ctx, uint32_t width, uint32_t height, void *d_fb, const float origin[3],
+                const float fwd[3], const float up[3], const float right[3], const vxrt_render_flags *flags);
+/* number of frame rows owned by a shard, = rows of its compact buffer */
+uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_count, int32_t strip_index);
+/* counters accumulated by the vxrt_render calls on this context since the previous read;
+ * synchronises the device, then clears them */
+int vxrt_frame_stats_get(vxrt_ctx *ctx, vxrt_frame_stats *out);
+/* scatter `strip_count` compact shard buffers (laid out back to back, shard-major, each padded to
+ * `shard_stride_bytes`) into a full W*H BGRA8 frame on the device; used by the root after the gather. */
+int vxrt_deinterleave_strips(vxrt_ctx *ctx, uint32_t width, uint32_t height, int32_t strip_rows,
+                             int32_t strip_count, const void *d_shards, uint64_t shard_stride_bytes,
+                             void *d_fb, void *stream);
+
+/* ---- batch query.  Replaces VoxelRaytracer3D::Raytrace + kernel dispatch
+ * (VoxelRT/VolumeRaytracer.cu:95-117,574-618).  Results follow the reference
+ * convention: miss -> point = +inf; normal (step direction, zero on a miss) and
+ * steps always written.  d_hit / d_voxel (optional) are this build's additions:
+ * hit flag and global hit voxel index x + X*(y + Y*z), -1 on a miss. */
+int vxrt_trace_batch(vxrt_ctx *ctx, const float *d_origins, const float *d_dirs, uint64_t n, float *d_pos,
+                     float *d_normal, int32_t *d_steps, uint8_t *d_hit, int64_t *d_voxel,
+                     vxrt_frame_stats *stats_or_null, void *stream);
+/* host-pointer convenience with the reference's copy-in / copy-out behaviour */
+int vxrt_trace_batch_host(vxrt_ctx *ctx, const float *origins, const float *dirs, uint64_t n, float *pos,
+                          float *normal, int32_t *steps, uint8_t *hit, int64_t *voxel,
+                          vxrt_frame_stats *stats_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VXRT_H */

@@ -1,0 +1,48 @@
+"""Shared scene/ray builders for the parity tests (seeded, small enough for the oracle to finish in seconds)."""
+import numpy as np
+
+CAMERAS = {  # position as a fraction of the world size, euler angles
+    "A": ((0.5, 0.9, 0.5), (-0.45, 0.7, 0.0)),
+    "B": ((0.1, 1.2, 0.1), (-0.6, 3.9, 0.0)),      # outside the grid
+    "C": ((0.5, 1.5, 0.5), (-1.5707, 0.0, 0.0)),   # top-down
+    "D": ((0.02, 0.55, 0.5), (-0.05, 1.5707, 0.0)),  # grazing
+}
+
+
+def random_voxel_world(vxo, size=(64, 64, 64), factor=8, density=0.01, seed=0):
+    rng = np.random.default_rng(seed)
+    v = rng.random(size) < density
+    return vxo.World.from_voxels(v, factor)
+
+
+def mixed_rays(dims, n, seed=0):
+    """Origins inside / outside / on cell edges, directions random, axis-aligned and with zero components."""
+    rng = np.random.default_rng(seed)
+    X, Y, Z = dims
+    o = np.empty((n, 3), np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    k = n // 6
+    o[:] = rng.random((n, 3)).astype(np.float32) * np.array([X, Y, Z], np.float32)          # inside
+    o[k:2 * k] = (rng.random((k, 3)).astype(np.float32) * 3 - 1) * np.array([X, Y, Z], np.float32)  # in/outside
+    o[2 * k:3 * k] = np.floor(o[2 * k:3 * k])                                                  # exact cell corners
+    o[3 * k:4 * k, 0] = np.float32(X)                                                          # on the +x face
+    d[3 * k:4 * k, 0] = -np.abs(d[3 * k:4 * k, 0])
+    ax = rng.integers(0, 3, size=k)                                                            # axis-aligned
+    d[4 * k:5 * k] = 0
+    d[np.arange(4 * k, 5 * k), ax] = rng.choice([-1.0, 1.0], size=k).astype(np.float32)
+    d[5 * k:6 * k, rng.integers(0, 3)] = 0                                                     # one zero component
+    # aim a share of the outside rays at the grid so they enter it
+    c = np.array([X, Y, Z], np.float32) / 2
+    aim = slice(k, k + k // 2)
+    d[aim] = (c + rng.normal(size=(k // 2, 3)).astype(np.float32) * c * 0.5) - o[aim]
+    bad = (np.abs(d).sum(axis=1) == 0)
+    d[bad] = (1, 0, 0)
+    return o, d
+
+
+def camera(name, dims, vxo_or_engine):
+    (fx, fy, fz), euler = CAMERAS[name]
+    pos = (fx * dims[0], fy * dims[1], fz * dims[2])
+    f, u, r = vxo_or_engine.get_directions(euler) if hasattr(vxo_or_engine, "get_directions") \
+        else vxo_or_engine.GetDirections(euler)
+    return pos, f, u, r

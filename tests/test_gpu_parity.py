@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+Integer/index outputs (hit, steps, voxel index, 8-bit pixels, probe counters) must be bit-exact; positions
+and normals are compared bit-exact too (same IEEE expressions on both sides); the float colour AOV within
+1e-4 per channel (north_star tolerance)."""
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+COLOR_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import torch
+    import voxelengine_amd as vx
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    ctx = vx.Context(0)
+    yield vx, ctx, torch
+    ctx.close()
+
+
+def _upload(ctx, w):
+    ctx.upload_world(w.factor, w.cdims, w.coarse_bits, w.brick_slot, w.bounds, w.pool)
+
+
+def _assert_batch_equal(gpu, cpu):
+    assert np.array_equal(gpu["hit"], cpu["hit"])
+    assert np.array_equal(gpu["steps"], cpu["steps"])
+    assert np.array_equal(gpu["voxel"], cpu["voxel"])
+    assert np.array_equal(gpu["hitPoint"].view(np.uint32), cpu["pos"].view(np.uint32))
+    assert np.array_equal(gpu["normal"].view(np.uint32) & 0x7FFFFFFF, cpu["normal"].view(np.uint32) & 0x7FFFFFFF)
+    assert np.array_equal(gpu["normal"], cpu["normal"])
+
+
+@pytest.mark.parametrize("factor,size,density,seed", [
+    (8, (64, 64, 64), 0.01, 1), (8, (128, 64, 64), 0.08, 2), (16, (128, 128, 128), 0.002, 3),
+    (32, (256, 256, 256), 0.0005, 4), (8, (64, 64, 64), 0.6, 5),
+])
+def test_trace_batch_random_worlds(eng, vxo, factor, size, density, seed):
+    vx, ctx, _ = eng
+    w = helpers.random_voxel_world(vxo, size, factor, density, seed)
+    _upload(ctx, w)
+    o, d = helpers.mixed_rays(w.dims, 30000, seed)
+    cpu = w.trace_batch(o, d)
+    gpu = ctx.Raytrace(o, d, want_stats=True)
+    _assert_batch_equal(gpu, cpu)
+    st = gpu["stats"]
+    assert (st.coarse_probes, st.brick_entries, st.fine_probes) == (
+        cpu["stats"].coarse_probes, cpu["stats"].brick_entries, cpu["stats"].fine_probes)
+    assert 0 < int(cpu["hit"].sum()) < len(o)
+
+
+def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
+    vx, ctx, _ = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    o, d = helpers.mixed_rays(w.dims, 60000, 9)
+    _assert_batch_equal(ctx.Raytrace(o, d), w.trace_batch(o, d))
+    out = ctx.Raytrace(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32))
+    assert out["steps"].shape == (0,)
+    # ragged tail (not a multiple of the workgroup size) and a single ray
+    _assert_batch_equal(ctx.Raytrace(o[:257], d[:257]), w.trace_batch(o[:257], d[:257]))
+    _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
+
+
+def test_known_answer_rays_on_gpu(eng, vxo):
+    """The hand-derived cases of tests/test_oracle_kat.py, through the HIP path."""
+    vx, ctx, _ = eng
+    v = np.zeros((64, 64, 64), bool)
+    for p in [(26, 12, 11), (26, 10, 11), (18, 11, 11)]:
+        v[p] = True
+    w = vxo.World.from_voxels(v, 8)
+    _upload(ctx, w)
+    r = ctx.Raytrace([(60.0, 11.5, 11.5)], [(-1, 0, 0)], want_stats=True)
+    up = np.nextafter(np.float32(1.4375), np.float32(np.inf))
+    yw = np.float32(np.float32(np.float32(up * np.float32(8)) - np.float32(8)) + np.float32(8))
+    assert r["steps"][0] == 13 and r["hit"][0] == 1
+    assert r["hitPoint"][0].tolist() == [19.0, float(yw), float(yw)]
+    assert r["normal"][0].tolist() == [-1, 0, 0]
+    assert r["voxel"][0] == 18 + 64 * (11 + 64 * 11)
+    assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == (6, 2, 10)
+
+
+def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
+    vx, ctx, torch = eng
+    pos, f, u, r = helpers.camera(cam, w.dims, vxo)
+    p = vxo.make_params(W, H, pos, f, u, r, frame_number=frame_number, **kw)
+    fb0 = np.random.default_rng(7).integers(0, 255, size=(H, W, 4), dtype=np.uint8)  # stale contents survive
+    cpu = w.render(p, fb=fb0.copy(), want_color=True, want_hit=True)
+    d_fb = torch.from_numpy(fb0.copy()).cuda()
+    d_col = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+    d_hit = torch.full((H, W), -1, dtype=torch.int64, device="cuda")
+    ctx.SetEnvironment(list(p.env.light_dir), list(p.env.light_color), list(p.env.ambient))
+    ctx.SetFOV(p.fov_deg)
+    ctx.SetOrthoWindowSize(p.ortho_size[0], p.ortho_size[1])
+    opts = vx.RenderOptions(mode=kw.get("mode", 0), checkerboard=bool(kw.get("checkerboard", 0)),
+                            shadow=bool(kw.get("shadow", 0)), bounce_samples=kw.get("bounce_samples", 0),
+                            bounce_all_hits=bool(kw.get("bounce_all_hits", 0)), ortho=bool(kw.get("ortho", 0)),
+                            frame_number=frame_number, collect_stats=True)
+    ctx.frame_stats()   # counters accumulate until read: start this frame from zero
+    ctx.RenderScreen(W, H, d_fb, pos, f, u, r, opts, color_aov=d_col, hit_aov=d_hit)
+    st = ctx.frame_stats()
+    return cpu, d_fb.cpu().numpy(), d_col.cpu().numpy(), d_hit.cpu().numpy(), st
+
+
+def _assert_frame_equal(cpu, fb, col, hit, st):
+    cst = cpu["stats"]
+    assert (st.primary_rays, st.shadow_rays, st.bounce_rays, st.primary_hits) == (
+        cst.primary_rays, cst.shadow_rays, cst.bounce_rays, cst.primary_hits)
+    assert (st.coarse_probes, st.brick_entries, st.fine_probes) == (
+        cst.probes.coarse_probes, cst.probes.brick_entries, cst.probes.fine_probes)
+    assert np.array_equal(hit, cpu["hit"])
+    assert np.nanmax(np.abs(col - cpu["color"])) <= COLOR_TOL
+    assert np.array_equal(fb, cpu["fb"])
+
+
+@pytest.mark.parametrize("cam", ["A", "B", "C", "D"])
+def test_render_shaded_primary_only(eng, vxo, cam):
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(eng[1], w)
+    cpu, fb, col, hit, st = _render_both(eng, vxo, w, 200, 120, cam)
+    _assert_frame_equal(cpu, fb, col, hit, st)
+    assert st.primary_rays == 200 * 120
+
+
+@pytest.mark.parametrize("cam,gate", [("A", 0), ("D", 0), ("A", 1)])
+def test_render_shadow_and_bounce(eng, vxo, cam, gate):
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(eng[1], w)
+    cpu, fb, col, hit, st = _render_both(eng, vxo, w, 192, 108, cam, frame_number=3, shadow=1, bounce_samples=1,
+                                         bounce_all_hits=gate)
+    _assert_frame_equal(cpu, fb, col, hit, st)
+    assert st.shadow_rays == st.primary_hits and st.bounce_rays > 0
+
+
+@pytest.mark.parametrize("frame", [0, 1])
+def test_render_checkerboard_and_debug_view(eng, vxo, frame):
+    """The shipped configuration: DEBUG_VIEW quadrants + checkerboard (Renderer.cu:4-5); only half the pixels
+    are written per frame, the rest keep their previous contents."""
+    w = vxo.World.generate(vxo.GEN_HASH_HEIGHTFIELD, 128, 128, 128, 16)
+    _upload(eng[1], w)
+    cpu, fb, col, hit, st = _render_both(eng, vxo, w, 160, 90, "A", frame_number=frame, mode=1, checkerboard=1)
+    _assert_frame_equal(cpu, fb, col, hit, st)
+    assert st.primary_rays < 160 * 90
+    cpu, fb, col, hit, st = _render_both(eng, vxo, w, 160, 90, "A", frame_number=frame, mode=0, checkerboard=1,
+                                         shadow=1, bounce_samples=2)
+    _assert_frame_equal(cpu, fb, col, hit, st)
+
+
+def test_render_ortho_and_f8(eng, vxo):
+    w = helpers.random_voxel_world(vxo, (128, 64, 128), 8, 0.03, 11)
+    _upload(eng[1], w)
+    cpu, fb, col, hit, st = _render_both(eng, vxo, w, 128, 96, "A", ortho=1, ortho_size=(30.0, 30.0), shadow=1)
+    _assert_frame_equal(cpu, fb, col, hit, st)
+    cpu, fb, col, hit, st = _render_both(eng, vxo, w, 133, 77, "B", shadow=1, bounce_samples=1)   # ragged frame
+    _assert_frame_equal(cpu, fb, col, hit, st)
+
+
+def test_context_frame_counter_matches_reference_increment(eng, vxo):
+    """RenderScreen copies hFrameInfo then increments FrameNumber (Renderer.cu:310,322): frames see 0,1,2..."""
+    vx, ctx, torch = eng
+    import ctypes as C
+    w = vxo.World.generate(vxo.GEN_HASH_HEIGHTFIELD, 128, 128, 128, 16)
+    c2 = vx.Context(0)
+    c2.upload_world(w.factor, w.cdims, w.coarse_bits, w.brick_slot, w.bounds, w.pool)
+    pos, f, u, r = helpers.camera("A", w.dims, vxo)
+    p0 = vxo.make_params(160, 90, pos, f, u, r)
+    c2.SetEnvironment(list(p0.env.light_dir), list(p0.env.light_color), list(p0.env.ambient))
+    for n in range(3):
+        d_fb = torch.full((90, 160, 4), 255, dtype=torch.uint8, device="cuda")
+        c2.RenderScreen(160, 90, d_fb, pos, f, u, r, vx.RenderOptions(checkerboard=True, bounce_samples=1))
+        p = vxo.make_params(160, 90, pos, f, u, r, frame_number=n, checkerboard=1, bounce_samples=1)
+        assert np.array_equal(d_fb.cpu().numpy(), w.render(p)["fb"])
+    c2.close()
+
+
+@pytest.mark.parametrize("count,rows", [(2, 16), (8, 16), (3, 8)])
+def test_strip_sharding_reassembles_the_frame(eng, vxo, count, rows):
+    """Each shard renders its interleaved strips into a packed buffer; de-interleaving the shard buffers gives
+    the single-GPU frame byte for byte."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    W, H = 192, 108
+    pos, f, u, r = helpers.camera("A", w.dims, vxo)
+    full = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    base = dict(shadow=True, bounce_samples=1, frame_number=2)
+    ctx.RenderScreen(W, H, full, pos, f, u, r, vx.RenderOptions(**base))
+    assert ctx.frame_stats().primary_rays == W * H
+    max_rows = max(vx.compact_rows(H, rows, count, i) for i in range(count))
+    stride = max_rows * W * 4
+    shards = torch.zeros((count, stride), dtype=torch.uint8, device="cuda")
+    total_primary = 0
+    for i in range(count):
+        ctx.RenderScreen(W, H, shards[i], pos, f, u, r,
+                         vx.RenderOptions(strip_rows=rows, strip_count=count, strip_index=i, compact=True, **base))
+        total_primary += ctx.frame_stats().primary_rays
+    out = torch.zeros_like(full)
+    ctx.deinterleave_strips(W, H, rows, count, shards, stride, out)
+    torch.cuda.synchronize()
+    assert total_primary == W * H
+    assert torch.equal(out, full)
+    p = vxo.make_params(W, H, pos, f, u, r, frame_number=2, shadow=1, bounce_samples=1)
+    assert np.array_equal(full.cpu().numpy(), w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"])
+
+
+@pytest.mark.parametrize("gen,shape,factor", [(0, (128, 128, 128), 16), (2, (256, 256, 256), 32),
+                                              (1, (128, 128, 128), 16), (2, (64, 64, 128), 8)])
+def test_device_world_builder_matches_oracle(eng, vxo, gen, shape, factor):
+    """vxrt_build_world_procedural produces the oracle's tables bit for bit (PERLIN_REF included: every float
+    op in the generator is exactly specified)."""
+    vx, ctx, _ = eng
+    info = ctx.build_world(gen, *shape, factor)
+    w = vxo.World.generate(gen, *shape, factor)
+    got = ctx.download_world()
+    assert info.nslots == w.nslots and tuple(info.cdims) == w.cdims
+    assert np.array_equal(got["coarse_bits"], w.coarse_bits)
+    assert np.array_equal(got["brick_slot"], w.brick_slot)
+    assert np.array_equal(got["bounds"], w.bounds)
+    assert np.array_equal(got["pool"], w.pool)
+
+
+def test_errors_are_reported_not_swallowed(eng, vxo):
+    vx, ctx, torch = eng
+    c2 = vx.Context(0)
+    with pytest.raises(vx.VxrtError):
+        c2.Raytrace([(0, 0, 0)], [(1, 0, 0)])            # no world resident
+    with pytest.raises(vx.VxrtError):
+        c2.build_world(0, 100, 100, 100, 32)               # not a multiple of the brick edge
+    with pytest.raises(vx.VxrtError):
+        c2.build_world(0, 128, 128, 128, 32)               # coarse dims not multiples of 8
+    c2.close()

@@ -1,0 +1,552 @@
+// vxrt_api.hip -- host side of the C ABI declared in include/vxrt.h.
+// Owns the HBM-resident world tables, the camera/lighting state the reference keeps in
+// process globals (hFrameInfo / g_env, VoxelRT/Renderer.cu:24-25,89) and the launches.
+#include "../../include/vxrt.h"
+#include "vxrt_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace vxrt {
+void launch_render(const RenderArgs& A, bool stats, hipStream_t stream);
+void launch_trace_batch(const BatchArgs& B, bool stats, hipStream_t stream);
+void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
+                         uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream);
+int build_world_on_device(struct ::vxrt_ctx* ctx, int generator, int X, int Y, int Z, int factor);
+}  // namespace vxrt
+
+static thread_local std::string g_last_error = "";
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define VX_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(VXRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+struct vxrt_ctx {
+    int device = 0;
+    // world
+    bool has_world = false;
+    vxrt::WorldView view{};
+    uint32_t* d_coarse = nullptr;
+    uint2* d_meta = nullptr;
+    uint32_t* d_pool = nullptr;
+    uint64_t ncells = 0, nslots = 0, pool_capacity_slots = 0;
+    // state the reference keeps in globals
+    float light_dir[3] = {0, 0, 0};  // g_env is a zero-initialised device global until SetEnvironment (Renderer.cu:89)
+    float light_color[3] = {0, 0, 0};
+    float ambient[3] = {0, 0, 0};
+    float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
+    float ortho[2] = {10.0f, 10.0f};
+    uint32_t frame_counter = 0;
+    unsigned long long* d_stats = nullptr;
+};
+
+namespace vxrt {
+
+static void free_world(vxrt_ctx* c)
+{
+    if (c->d_coarse) (void)hipFree(c->d_coarse);
+    if (c->d_meta) (void)hipFree(c->d_meta);
+    if (c->d_pool) (void)hipFree(c->d_pool);
+    c->d_coarse = nullptr;
+    c->d_meta = nullptr;
+    c->d_pool = nullptr;
+    c->has_world = false;
+    c->ncells = c->nslots = c->pool_capacity_slots = 0;
+}
+
+// shared by upload and the device builder
+int check_shape(int factor, const int cd[3])
+{
+    if (!(factor == 8 || factor == 16 || factor == 32))
+        return fail(VXRT_ERR_INVALID, "factor must be 8, 16 or 32");
+    for (int a = 0; a < 3; ++a)
+        if (cd[a] <= 0 || cd[a] % 8 != 0 || cd[a] > 65535)
+            return fail(VXRT_ERR_INVALID, "coarse dimensions must be positive multiples of 8 (tiled-linear layout)");
+    return VXRT_OK;
+}
+
+void fill_view(vxrt_ctx* c, int factor, const int cd[3])
+{
+    WorldView& v = c->view;
+    v.coarse_bits = c->d_coarse;
+    v.cell_meta = c->d_meta;
+    v.pool = c->d_pool;
+    v.cx = cd[0];
+    v.cy = cd[1];
+    v.cz = cd[2];
+    v.ctw = cd[0] / 8;
+    v.ctwh = (cd[0] / 8) * (cd[1] / 8);
+    v.f = factor;
+    v.ftw = factor / 8;
+    v.ftwh = (factor / 8) * (factor / 8);
+    v.brick_words = (uint32_t)(factor * factor * factor / 32);
+    v.ff = (float)factor;
+    v.inv_f = 1.0f / (float)factor;
+    v.wmax_x = (float)((double)cd[0] - 1e-6);  // dims - FLT_EPS_DDA in double, VolumeRaytracer.cu:375-376
+    v.wmax_y = (float)((double)cd[1] - 1e-6);
+    v.wmax_z = (float)((double)cd[2] - 1e-6);
+    v.X = cd[0] * factor;
+    v.Y = cd[1] * factor;
+}
+
+int alloc_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t pool_slots)
+{
+    free_world(c);
+    c->ncells = (uint64_t)cd[0] * cd[1] * cd[2];
+    uint64_t bw = (uint64_t)factor * factor * factor / 32;
+    VX_HIP(hipMalloc((void**)&c->d_coarse, ((c->ncells + 31) / 32) * sizeof(uint32_t)));
+    VX_HIP(hipMalloc((void**)&c->d_meta, c->ncells * sizeof(uint2)));
+    VX_HIP(hipMalloc((void**)&c->d_pool, (pool_slots ? pool_slots : 1) * bw * sizeof(uint32_t)));
+    c->pool_capacity_slots = pool_slots;
+    return VXRT_OK;
+}
+
+int adopt_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t nslots, uint32_t** d_coarse, uint2** d_meta,
+                uint32_t** d_pool)
+{
+    int rc = alloc_world(c, factor, cd, nslots);
+    if (rc)
+        return rc;
+    c->nslots = nslots;
+    fill_view(c, factor, cd);
+    c->has_world = true;
+    *d_coarse = c->d_coarse;
+    *d_meta = c->d_meta;
+    *d_pool = c->d_pool;
+    return VXRT_OK;
+}
+
+int set_error(int code, const char* msg) { return fail(code, msg); }
+
+}  // namespace vxrt
+
+extern "C" {
+
+int vxrt_abi_version(void) { return VXRT_ABI_VERSION; }
+
+const char* vxrt_last_error(void) { return g_last_error.c_str(); }
+
+int vxrt_create(int device, vxrt_ctx** out)
+{
+    if (!out)
+        return fail(VXRT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    VX_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(VXRT_ERR_INVALID, "no such HIP device");
+    VX_HIP(hipSetDevice(device));
+    vxrt_ctx* c = new (std::nothrow) vxrt_ctx();
+    if (!c)
+        return fail(VXRT_ERR_NOMEM, "out of host memory");
+    c->device = device;
+    hipError_t e = hipMalloc((void**)&c->d_stats, vxrt::kStatCount * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMemset(c->d_stats, 0, vxrt::kStatCount * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        delete c;
+        return fail(VXRT_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
+    }
+    *out = c;
+    return VXRT_OK;
+}
+
+int vxrt_destroy(vxrt_ctx* c)
+{
+    if (!c)
+        return VXRT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    vxrt::free_world(c);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    delete c;
+    return VXRT_OK;
+}
+
+int vxrt_synchronize(vxrt_ctx* c)
+{
+    if (!c)
+        return fail(VXRT_ERR_INVALID, "ctx is NULL");
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());
+    return VXRT_OK;
+}
+
+int vxrt_upload_world(vxrt_ctx* c, const vxrt_world_desc* d)
+{
+    if (!c || !d || d->struct_size != sizeof(vxrt_world_desc))
+        return fail(VXRT_ERR_INVALID, "bad ctx/desc");
+    if (!d->coarse_bits || !d->brick_slot || !d->bounds || (d->nslots && !d->pool))
+        return fail(VXRT_ERR_INVALID, "NULL table");
+    int cd[3] = {d->cdims[0], d->cdims[1], d->cdims[2]};
+    int rc = vxrt::check_shape(d->factor, cd);
+    if (rc)
+        return rc;
+    VX_HIP(hipSetDevice(c->device));
+    const int f = d->factor;
+    const uint64_t ncells = (uint64_t)cd[0] * cd[1] * cd[2];
+    // flatten {descriptor, bounds} pairs into 8-byte cell_meta records
+    std::vector<uint2> meta(ncells);
+    for (uint64_t i = 0; i < ncells; ++i) {
+        bool bit = (d->coarse_bits[i >> 5] >> (i & 31)) & 1u;
+        uint32_t slot = d->brick_slot[i];
+        const float* b = d->bounds + i * 6;
+        uint32_t packed = 0;
+        if (bit) {
+            if (slot == VXRT_EMPTY_SLOT || slot >= d->nslots)
+                return fail(VXRT_ERR_INVALID, "occupied coarse cell without a valid brick slot");
+            for (int k = 0; k < 6; ++k) {
+                float v = b[k];
+                if (!(v >= 0.0f && v <= (float)(f - 1) && v == (float)(int)v))
+                    return fail(VXRT_ERR_INVALID, "brick extents must be integers in [0, factor-1]");
+                packed |= (uint32_t)(int)v << (5 * k);
+            }
+        } else {
+            slot = VXRT_EMPTY_SLOT;
+        }
+        meta[i] = make_uint2(slot, packed);
+    }
+    rc = vxrt::alloc_world(c, f, cd, d->nslots);
+    if (rc)
+        return rc;
+    const uint64_t bw = (uint64_t)f * f * f / 32;
+    VX_HIP(hipMemcpy(c->d_coarse, d->coarse_bits, ((ncells + 31) / 32) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    VX_HIP(hipMemcpy(c->d_meta, meta.data(), ncells * sizeof(uint2), hipMemcpyHostToDevice));
+    if (d->nslots)
+        VX_HIP(hipMemcpy(c->d_pool, d->pool, d->nslots * bw * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->nslots = d->nslots;
+    vxrt::fill_view(c, f, cd);
+    c->has_world = true;
+    return VXRT_OK;
+}
+
+int vxrt_build_world_procedural(vxrt_ctx* c, int generator, int X, int Y, int Z, int factor)
+{
+    if (!c)
+        return fail(VXRT_ERR_INVALID, "ctx is NULL");
+    VX_HIP(hipSetDevice(c->device));
+    return vxrt::build_world_on_device(c, generator, X, Y, Z, factor);
+}
+
+int vxrt_world_info_get(vxrt_ctx* c, vxrt_world_info* out)
+{
+    if (!c || !out)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (!c->has_world)
+        return fail(VXRT_ERR_NO_WORLD, "no world resident");
+    out->factor = c->view.f;
+    out->cdims[0] = c->view.cx;
+    out->cdims[1] = c->view.cy;
+    out->cdims[2] = c->view.cz;
+    out->ncells = c->ncells;
+    out->nslots = c->nslots;
+    out->hbm_bytes = ((c->ncells + 31) / 32) * 4 + c->ncells * sizeof(uint2) + c->nslots * c->view.brick_words * 4ull;
+    return VXRT_OK;
+}
+
+int vxrt_download_world(vxrt_ctx* c, uint32_t* coarse_bits, uint32_t* brick_slot, float* bounds, uint32_t* pool)
+{
+    if (!c || !coarse_bits || !brick_slot || !bounds)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (!c->has_world)
+        return fail(VXRT_ERR_NO_WORLD, "no world resident");
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());
+    VX_HIP(hipMemcpy(coarse_bits, c->d_coarse, ((c->ncells + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint2> meta(c->ncells);
+    VX_HIP(hipMemcpy(meta.data(), c->d_meta, c->ncells * sizeof(uint2), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < c->ncells; ++i) {
+        brick_slot[i] = meta[i].x;
+        float* b = bounds + i * 6;
+        if (meta[i].x == VXRT_EMPTY_SLOT) {
+            b[0] = b[1] = b[2] = 0.0f;
+            b[3] = b[4] = b[5] = -1.0f;  // VolumeRaytracer.cuh:454-467
+        } else {
+            for (int k = 0; k < 6; ++k)
+                b[k] = (float)((meta[i].y >> (5 * k)) & 31u);
+        }
+    }
+    if (pool && c->nslots)
+        VX_HIP(hipMemcpy(pool, c->d_pool, c->nslots * c->view.brick_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return VXRT_OK;
+}
+
+int vxrt_set_environment(vxrt_ctx* c, const float light_dir[3], const float light_color[3], const float ambient[3])
+{
+    if (!c || !light_dir || !light_color || !ambient)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    memcpy(c->light_dir, light_dir, sizeof(c->light_dir));
+    memcpy(c->light_color, light_color, sizeof(c->light_color));
+    memcpy(c->ambient, ambient, sizeof(c->ambient));
+    return VXRT_OK;
+}
+
+int vxrt_set_fov(vxrt_ctx* c, float fov_degrees)
+{
+    if (!c)
+        return fail(VXRT_ERR_INVALID, "ctx is NULL");
+    c->fov = fov_degrees;
+    return VXRT_OK;
+}
+
+int vxrt_set_ortho_window_size(vxrt_ctx* c, float sx, float sy)
+{
+    if (!c)
+        return fail(VXRT_ERR_INVALID, "ctx is NULL");
+    c->ortho[0] = sx;
+    c->ortho[1] = sy;
+    return VXRT_OK;
+}
+
+// GetDirections (Renderer.cu:27-42): float cos/sin, forward and up negated on return
+void vxrt_get_directions(const float euler[3], float fwd[3], float up[3], float right[3])
+{
+    float fx = cosf(euler[0]) * sinf(euler[1]);
+    float fy = -sinf(euler[0]);
+    float fz = cosf(euler[0]) * cosf(euler[1]);
+    float rx = cosf(euler[1]), ry = 0.0f, rz = -sinf(euler[1]);
+    float ux = fy * rz - fz * ry, uy = fz * rx - fx * rz, uz = fx * ry - fy * rx;
+    fwd[0] = fx * -1;
+    fwd[1] = fy * -1;
+    fwd[2] = fz * -1;
+    up[0] = ux * -1;
+    up[1] = uy * -1;
+    up[2] = uz * -1;
+    right[0] = rx;
+    right[1] = ry;
+    right[2] = rz;
+}
+
+void vxrt_render_flags_default(vxrt_render_flags* f)
+{
+    if (!f)
+        return;
+    memset(f, 0, sizeof(*f));
+    f->struct_size = sizeof(*f);
+    f->mode = VXRT_MODE_SHADED;
+    f->frame_number = -1;
+    f->strip_rows = 16;
+    f->strip_count = 1;
+}
+
+uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_count, int32_t strip_index)
+{
+    if (strip_rows <= 0 || strip_count <= 1)
+        return height;
+    uint32_t rows = 0;
+    uint32_t nstrips = (height + (uint32_t)strip_rows - 1) / (uint32_t)strip_rows;
+    for (uint32_t s = (uint32_t)strip_index; s < nstrips; s += (uint32_t)strip_count) {
+        uint32_t begin = s * (uint32_t)strip_rows;
+        uint32_t end = begin + (uint32_t)strip_rows < height ? begin + (uint32_t)strip_rows : height;
+        rows += end - begin;
+    }
+    return rows;
+}
+
+int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const float origin[3], const float fwd[3],
+                const float up[3], const float right[3], const vxrt_render_flags* fl)
+{
+    if (!c || !d_fb || !origin || !fwd || !up || !right)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    vxrt_render_flags def;
+    if (!fl) {
+        vxrt_render_flags_default(&def);
+        fl = &def;
+    }
+    if (fl->struct_size != sizeof(vxrt_render_flags))
+        return fail(VXRT_ERR_INVALID, "vxrt_render_flags size mismatch");
+    if (!c->has_world)
+        return fail(VXRT_ERR_NO_WORLD, "no world resident");
+    if (width == 0 || height == 0)
+        return fail(VXRT_ERR_INVALID, "empty frame");
+    if (fl->strip_count > 1 && (fl->strip_rows <= 0 || fl->strip_index < 0 || fl->strip_index >= fl->strip_count))
+        return fail(VXRT_ERR_INVALID, "bad strip sharding");
+    VX_HIP(hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)fl->stream;
+
+    vxrt::RenderArgs A;
+    memset(&A, 0, sizeof(A));
+    A.W = c->view;
+    A.width = width;
+    A.height = height;
+    if (fl->frame_number >= 0) {
+        A.frame_number = (uint32_t)fl->frame_number;
+    } else {
+        A.frame_number = c->frame_counter;  // the copy precedes the increment, Renderer.cu:310,322
+        c->frame_counter += 1;
+    }
+    {   // getRayDirection's per-pixel constants (Renderer.cu:46,50-52), hoisted to the host
+        float aspect = (float)width / (float)height;
+        float fov = (float)((double)c->fov * 3.1415 / 180.0);
+        A.kx = tanf(fov / 2.0f) * aspect;
+        A.ky = tanf(fov / 2.0f);
+        A.ratio = (float)width / (float)height;
+        A.ortho_x = c->ortho[0];
+        A.ortho_y = c->ortho[1];
+    }
+    A.origin = vxrt::f3{origin[0], origin[1], origin[2]};
+    A.fwd = vxrt::f3{fwd[0], fwd[1], fwd[2]};
+    A.up = vxrt::f3{up[0], up[1], up[2]};
+    A.right = vxrt::f3{right[0], right[1], right[2]};
+    A.light_dir = vxrt::f3{c->light_dir[0], c->light_dir[1], c->light_dir[2]};
+    A.light_color = vxrt::f3{c->light_color[0], c->light_color[1], c->light_color[2]};
+    A.ambient = vxrt::f3{c->ambient[0], c->ambient[1], c->ambient[2]};
+    A.mode = fl->mode;
+    A.checkerboard = fl->checkerboard ? 1 : 0;
+    A.shadow = fl->shadow ? 1 : 0;
+    A.bounce_samples = fl->bounce_samples < 0 ? 0 : fl->bounce_samples;
+    A.bounce_all_hits = fl->bounce_all_hits ? 1 : 0;
+    A.ortho = fl->ortho ? 1 : 0;
+    A.strip_rows = fl->strip_rows > 0 ? fl->strip_rows : 16;
+    A.strip_count = fl->strip_count > 1 ? fl->strip_count : 1;
+    A.strip_index = fl->strip_index;
+    A.compact = fl->compact ? 1 : 0;
+    // launch shape: RenderScreen halves the rows under checkerboard (Renderer.cu:311-316); a shard
+    // without checkerboard launches only its own rows
+    if (A.checkerboard)
+        A.launch_rows = height >> 1;
+    else if (A.strip_count > 1)
+        A.launch_rows = vxrt_compact_rows(height, A.strip_rows, A.strip_count, A.strip_index);
+    else
+        A.launch_rows = height;
+    A.fb = (uint8_t*)d_fb;
+    A.color_aov = fl->d_color_aov;
+    A.hit_aov = (long long*)fl->d_hit_aov;
+    A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
+    vxrt::launch_render(A, fl->collect_stats != 0, stream);
+    VX_HIP(hipGetLastError());
+    return VXRT_OK;
+}
+
+int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
+{
+    if (!c || !out)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());
+    unsigned long long h[vxrt::kStatCount];
+    VX_HIP(hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    VX_HIP(hipMemset(c->d_stats, 0, sizeof(h)));
+    out->primary_rays = h[vxrt::kStatPrimary];
+    out->shadow_rays = h[vxrt::kStatShadow];
+    out->bounce_rays = h[vxrt::kStatBounce];
+    out->primary_hits = h[vxrt::kStatPrimaryHits];
+    out->coarse_probes = h[vxrt::kStatCoarseProbes];
+    out->brick_entries = h[vxrt::kStatBrickEntries];
+    out->fine_probes = h[vxrt::kStatFineProbes];
+    return VXRT_OK;
+}
+
+int vxrt_deinterleave_strips(vxrt_ctx* c, uint32_t width, uint32_t height, int32_t strip_rows, int32_t strip_count,
+                             const void* d_shards, uint64_t shard_stride_bytes, void* d_fb, void* stream)
+{
+    if (!c || !d_shards || !d_fb)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (width % 4 != 0 || shard_stride_bytes % 16 != 0 || strip_rows <= 0 || strip_count <= 0)
+        return fail(VXRT_ERR_INVALID, "width must be a multiple of 4 pixels and the shard stride of 16 bytes");
+    VX_HIP(hipSetDevice(c->device));
+    vxrt::launch_deinterleave(d_shards, shard_stride_bytes, d_fb, width, height, (uint32_t)strip_rows,
+                              (uint32_t)strip_count, (hipStream_t)stream);
+    VX_HIP(hipGetLastError());
+    return VXRT_OK;
+}
+
+int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, uint64_t n, float* d_pos,
+                     float* d_normal, int32_t* d_steps, uint8_t* d_hit, int64_t* d_voxel, vxrt_frame_stats* stats,
+                     void* stream_)
+{
+    if (!c || (n && (!d_origins || !d_dirs || !d_pos || !d_normal || !d_steps)))
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (!c->has_world)
+        return fail(VXRT_ERR_NO_WORLD, "no world resident");
+    VX_HIP(hipSetDevice(c->device));
+    hipStream_t stream = (hipStream_t)stream_;
+    vxrt::BatchArgs B;
+    memset(&B, 0, sizeof(B));
+    B.W = c->view;
+    B.origins = d_origins;
+    B.dirs = d_dirs;
+    B.n = n;
+    B.pos = d_pos;
+    B.normal = d_normal;
+    B.steps = d_steps;
+    B.hit = d_hit;
+    B.voxel = (long long*)d_voxel;
+    B.stats = c->d_stats;
+    if (stats) {  // a stats request reports this batch alone
+        VX_HIP(hipDeviceSynchronize());
+        VX_HIP(hipMemset(c->d_stats, 0, vxrt::kStatCount * sizeof(unsigned long long)));
+    }
+    vxrt::launch_trace_batch(B, stats != nullptr, stream);
+    VX_HIP(hipGetLastError());
+    if (stats) {
+        VX_HIP(hipStreamSynchronize(stream));
+        return vxrt_frame_stats_get(c, stats);
+    }
+    return VXRT_OK;
+}
+
+int vxrt_trace_batch_host(vxrt_ctx* c, const float* origins, const float* dirs, uint64_t n, float* pos, float* normal,
+                          int32_t* steps, uint8_t* hit, int64_t* voxel, vxrt_frame_stats* stats)
+{
+    if (!c || (n && (!origins || !dirs || !pos || !normal || !steps)))
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (!c->has_world)
+        return fail(VXRT_ERR_NO_WORLD, "no world resident");
+    if (n == 0)
+        return VXRT_OK;
+    VX_HIP(hipSetDevice(c->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_p = nullptr, *d_n = nullptr;
+    int32_t* d_s = nullptr;
+    uint8_t* d_h = nullptr;
+    int64_t* d_v = nullptr;
+    int rc = VXRT_OK;
+    auto cleanup = [&]() {
+        (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_p); (void)hipFree(d_n);
+        (void)hipFree(d_s); (void)hipFree(d_h); (void)hipFree(d_v);
+    };
+#define VX_TRY(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            cleanup();                                                                     \
+            return fail(VXRT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));  \
+        }                                                                                  \
+    } while (0)
+    VX_TRY(hipMalloc((void**)&d_o, n * 12));
+    VX_TRY(hipMalloc((void**)&d_d, n * 12));
+    VX_TRY(hipMalloc((void**)&d_p, n * 12));
+    VX_TRY(hipMalloc((void**)&d_n, n * 12));
+    VX_TRY(hipMalloc((void**)&d_s, n * 4));
+    VX_TRY(hipMalloc((void**)&d_h, n));
+    VX_TRY(hipMalloc((void**)&d_v, n * 8));
+    VX_TRY(hipMemcpy(d_o, origins, n * 12, hipMemcpyHostToDevice));
+    VX_TRY(hipMemcpy(d_d, dirs, n * 12, hipMemcpyHostToDevice));
+    rc = vxrt_trace_batch(c, d_o, d_d, n, d_p, d_n, d_s, d_h, d_v, stats, nullptr);
+    if (rc == VXRT_OK) {
+        VX_TRY(hipDeviceSynchronize());
+        VX_TRY(hipMemcpy(pos, d_p, n * 12, hipMemcpyDeviceToHost));
+        VX_TRY(hipMemcpy(normal, d_n, n * 12, hipMemcpyDeviceToHost));
+        VX_TRY(hipMemcpy(steps, d_s, n * 4, hipMemcpyDeviceToHost));
+        if (hit) VX_TRY(hipMemcpy(hit, d_h, n, hipMemcpyDeviceToHost));
+        if (voxel) VX_TRY(hipMemcpy(voxel, d_v, n * 8, hipMemcpyDeviceToHost));
+    }
+#undef VX_TRY
+    cleanup();
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,328 @@
+// vxrt_device.hpp -- gfx950 device code shared by the kernels of libvxrt.so.
+//
+// HBM layout of a resident world:
+//   coarse_bits : u32 words, one bit per brick cell, 8x8x8 tiled-linear order
+//                 (bit order of GetSampleIndex, VoxelRT/VolumeRaytracer.cuh:107-131)
+//   cell_meta   : one uint2 per brick cell in the same order:
+//                 .x = pool slot of the brick (VXRT_EMPTY_SLOT if empty)
+//                 .y = tight extents, 6 x 5 bits {min x,y,z, max x,y,z}
+//                 (replaces the 24-byte VoxelBuffer3D descriptor + 24-byte Bounds3Df per cell)
+//   pool        : u32 words, nslots bricks of f^3 bits, tiled-linear inside each brick
+//
+// All float arithmetic mirrors the reference expression by expression and is
+// compiled with -ffp-contract=off so results are IEEE binary32, bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vxrt {
+
+constexpr int kMaxSteps = 2048;               // MAX_STEPS, VolumeRaytracer.cuh:235
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+constexpr float kInf = __builtin_huge_valf();
+constexpr float kFltEps = 1.1920928955078125e-7f;  // FLT_EPS, VolumeRaytracer.cuh:22
+
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// plain comparisons, like the host fminf/fmaxf of helper_math.h:56-64 (no NaN / signed-zero special cases)
+__device__ __forceinline__ float lo(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float hi(float a, float b) { return a > b ? a : b; }
+// normalize: v * (1/sqrt(dot)) with correctly rounded sqrt and divide (helper_math.h:78-81,1325-1329)
+__device__ __forceinline__ f3 unit3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+// reflect(i, n) = i - 2n*dot(n,i) (helper_math.h:1427-1430)
+__device__ __forceinline__ f3 reflect3(f3 i, f3 n) { return i - (n * 2.0f) * dot3(n, i); }
+
+struct WorldView {
+    const uint32_t* __restrict__ coarse_bits;
+    const uint2* __restrict__ cell_meta;
+    const uint32_t* __restrict__ pool;
+    int cx, cy, cz;        // coarse cells per axis
+    int ctw, ctwh;         // coarse tiles per row, per slice
+    int f;                 // brick edge (8, 16, 32)
+    int ftw, ftwh;         // brick tiles per row, per slice
+    uint32_t brick_words;  // f^3 / 32
+    float ff;              // (float)f
+    float inv_f;           // 1/f, exact because f is a power of two: x / f == x * inv_f bit for bit
+    float wmax_x, wmax_y, wmax_z;  // (float)((double)c - 1e-6), VolumeRaytracer.cu:375-376
+    int X, Y;              // world voxels per axis (hit voxel index)
+};
+
+struct RayCounters {
+    uint32_t coarse_probes, brick_entries, fine_probes;
+};
+
+// 8x8x8 tiled-linear bit address (GetSampleIndex, VolumeRaytracer.cuh:107-131)
+__device__ __forceinline__ uint32_t tiled_index(int x, int y, int z, int tw, int twh)
+{
+    uint32_t tile = (uint32_t)((x >> 3) + (y >> 3) * tw + (z >> 3) * twh);
+    return tile * 512u + (uint32_t)((x & 7) | ((y & 7) << 3) | ((z & 7) << 6));
+}
+
+// nextafterf(v, neg ? -inf : +inf) by bit manipulation (VolumeRaytracer.cu:452-460)
+__device__ __forceinline__ float ulp_step(float v, bool neg)
+{
+    uint32_t b = __float_as_uint(v);
+    uint32_t mag = b & 0x7FFFFFFFu;
+    if (mag > 0x7F800000u)
+        return v;  // NaN
+    if (mag == 0u)
+        return __uint_as_float(neg ? 0x80000001u : 0x00000001u);
+    bool negative = (b >> 31) != 0u;
+    if (mag == 0x7F800000u && negative == neg)
+        return v;  // already at the infinity we walk toward
+    return __uint_as_float(negative == neg ? b + 1u : b - 1u);
+}
+
+// RayIntersectsAABB (VolumeRaytracer.cu:124-174)
+__device__ __forceinline__ bool ray_box(f3 s, f3 d, f3 bmin, f3 bmax, f3& p, f3& n)
+{
+    float ix = 1.0f / (d.x == 0 ? kFltEps : d.x);
+    float iy = 1.0f / (d.y == 0 ? kFltEps : d.y);
+    float iz = 1.0f / (d.z == 0 ? kFltEps : d.z);
+    float ax = (bmin.x - s.x) * ix, bx = (bmax.x - s.x) * ix;
+    float ay = (bmin.y - s.y) * iy, by = (bmax.y - s.y) * iy;
+    float az = (bmin.z - s.z) * iz, bz = (bmax.z - s.z) * iz;
+    float nx = lo(ax, bx), fx = hi(ax, bx);
+    float ny = lo(ay, by), fy = hi(ay, by);
+    float nz = lo(az, bz), fz = hi(az, bz);
+    float t_in = hi(hi(nx, ny), nz);
+    float t_out = lo(lo(fx, fy), fz);
+    if (t_out < hi(t_in, 0.0f))
+        return false;
+    p = mk3(s.x + t_in * d.x, s.y + t_in * d.y, s.z + t_in * d.z);
+    if (t_in == nx)
+        n = mk3(ix < 0.0f ? -1.0f : 1.0f, 0.0f, 0.0f);
+    else if (t_in == ny)
+        n = mk3(0.0f, iy < 0.0f ? -1.0f : 1.0f, 0.0f);
+    else
+        n = mk3(0.0f, 0.0f, iz < 0.0f ? -1.0f : 1.0f);
+    return true;
+}
+
+struct WalkResult {
+    bool hit, oob;
+    int hx, hy, hz;     // HitCell (clamped cell of the last in-range probe)
+    int ncx, ncy, ncz;  // NextCell
+    f3 point;           // HitIntersectedPoint
+    f3 normal;          // HitNormal
+    int steps;          // stepsTaken
+};
+
+// DDARayTraversal (VolumeRaytracer.cu:176-352), straightforward form: one call walks one
+// level from `s` until a hit or the exit.  COARSE: per-cell tight boxes from cell_meta are
+// tested from the walk's start (:248-273); otherwise the region check [0,f]^3 on the crossing
+// point applies (:325-341).
+template <bool COARSE>
+__device__ void walk_level(const WorldView& W, const uint32_t* __restrict__ bits, int dim_x, int dim_y, int dim_z,
+                           int tw, int twh, f3 s, f3 d, WalkResult& R, uint32_t& probes)
+{
+    int cell_x = (int)s.x, cell_y = (int)s.y, cell_z = (int)s.z;
+    const int sgn_x = d.x > 0 ? 1 : -1, sgn_y = d.y > 0 ? 1 : -1, sgn_z = d.z > 0 ? 1 : -1;
+    const float td_x = d.x != 0 ? fabsf(1.0f / d.x) : kInf;
+    const float td_y = d.y != 0 ? fabsf(1.0f / d.y) : kInf;
+    const float td_z = d.z != 0 ? fabsf(1.0f / d.z) : kInf;
+    float tn_x = d.x != 0 ? ((float)(cell_x + (sgn_x > 0)) - s.x) / d.x : kInf;
+    float tn_y = d.y != 0 ? ((float)(cell_y + (sgn_y > 0)) - s.y) / d.y : kInf;
+    float tn_z = d.z != 0 ? ((float)(cell_z + (sgn_z > 0)) - s.z) / d.z : kInf;
+
+    R.hit = false;
+    R.oob = false;
+    R.hx = R.hy = R.hz = 0;
+    R.ncx = R.ncy = R.ncz = 0;
+    R.point = s;
+    R.normal = mk3(0, 0, 0);
+    R.steps = 0;
+
+    int pad_x = 0, pad_y = 0, pad_z = 0;  // edge rule, :216-232
+    if (cell_x == dim_x || cell_y == dim_y || cell_z == dim_z) {
+        pad_x = d.x < 0;
+        pad_y = d.y < 0;
+        pad_z = d.z < 0;
+    }
+
+    bool leaving = false;
+    for (int it = 0; it < kMaxSteps; ++it) {
+        bool inside = 0 <= cell_x && cell_x < dim_x + pad_x && 0 <= cell_y && cell_y < dim_y + pad_y &&
+                      0 <= cell_z && cell_z < dim_z + pad_z;
+        if (inside) {
+            int qx = min(max(cell_x, 0), dim_x - 1), qy = min(max(cell_y, 0), dim_y - 1),
+                qz = min(max(cell_z, 0), dim_z - 1);
+            R.hx = qx;
+            R.hy = qy;
+            R.hz = qz;
+            probes += 1;
+            uint32_t idx = tiled_index(qx, qy, qz, tw, twh);
+            bool solid = bits ? ((bits[idx >> 5] >> (idx & 31u)) & 1u) != 0u : false;
+            if (COARSE) {
+                if (solid) {
+                    uint32_t e = W.cell_meta[idx].y;
+                    f3 bmin = mk3(((float)(e & 31u) + 0) * W.inv_f + (float)qx,
+                                  ((float)((e >> 5) & 31u) + 0) * W.inv_f + (float)qy,
+                                  ((float)((e >> 10) & 31u) + 0) * W.inv_f + (float)qz);
+                    f3 bmax = mk3(((float)((e >> 15) & 31u) + 1) * W.inv_f + (float)qx,
+                                  ((float)((e >> 20) & 31u) + 1) * W.inv_f + (float)qy,
+                                  ((float)((e >> 25) & 31u) + 1) * W.inv_f + (float)qz);
+                    f3 bp, bn;
+                    if (bmin.x <= bmax.x && ray_box(s, d, bmin, bmax, bp, bn)) {
+                        R.hit = true;
+                        R.normal = bn;
+                        if (it != 0)
+                            R.point = bp;
+                        leaving = true;
+                    }
+                }
+            } else if (solid) {
+                R.hit = true;
+                leaving = true;
+            }
+        } else {
+            R.oob = true;
+            leaving = true;
+        }
+
+        // advance one cell, also on the exit iteration (:290-322)
+        f3 cross;
+        f3 step_n;
+        if (tn_x < tn_y && tn_x < tn_z) {
+            cross = mk3((float)(cell_x + (sgn_x > 0)), s.y + (tn_x * d.y), s.z + (tn_x * d.z));
+            cell_x += sgn_x;
+            tn_x += td_x;
+            step_n = mk3((float)sgn_x, 0, 0);
+        } else if (tn_y <= tn_x && tn_y < tn_z) {
+            cross = mk3(s.x + (tn_y * d.x), (float)(cell_y + (sgn_y > 0)), s.z + (tn_y * d.z));
+            cell_y += sgn_y;
+            tn_y += td_y;
+            step_n = mk3(0, (float)sgn_y, 0);
+        } else {
+            cross = mk3(s.x + (tn_z * d.x), s.y + (tn_z * d.y), (float)(cell_z + (sgn_z > 0)));
+            cell_z += sgn_z;
+            tn_z += td_z;
+            step_n = mk3(0, 0, (float)sgn_z);
+        }
+        if (leaving) {
+            R.ncx = cell_x;
+            R.ncy = cell_y;
+            R.ncz = cell_z;
+            break;
+        }
+        R.normal = step_n;
+        if (!COARSE) {
+            // region [0,f]^3, int-truncated and inclusive, tested on the crossing point (:325-341)
+            const float fmax = W.ff;
+            if (cross.x < 0.0f || cross.x > fmax || cross.y < 0.0f || cross.y > fmax || cross.z < 0.0f ||
+                cross.z > fmax) {
+                R.oob = true;
+                break;
+            }
+        }
+        R.steps += 1;
+        R.point = cross;
+    }
+}
+
+struct TraceResult {
+    bool hit;
+    int steps;
+    f3 pos;     // valid on hit
+    f3 normal;  // step-direction convention; zero on a miss
+    int vx, vy, vz;  // global voxel that ended the ray (valid on hit)
+};
+
+// Raytrace (VolumeRaytracer.cu:354-525), straightforward form.
+__device__ void trace_direct(const WorldView& W, int max_steps, f3 origin, f3 ray, TraceResult& out, RayCounters& cnt)
+{
+    float last_x = -1, last_y = -1, last_z = -1;
+    int total = 0;
+    f3 start = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);  // origin / factor
+    const f3 dir = unit3(ray);
+    f3 entry_n = mk3(0, 0, 0);
+    if (!(start.x >= 0 && start.y >= 0 && start.z >= 0 && start.x < (float)W.cx && start.y < (float)W.cy &&
+          start.z < (float)W.cz)) {
+        const float e = (float)1e-6;
+        f3 p, n;
+        if (ray_box(start, dir, mk3(e, e, e), mk3(W.wmax_x, W.wmax_y, W.wmax_z), p, n)) {
+            start = p;
+            entry_n = n;
+        }
+    }
+    out.normal = mk3(0, 0, 0);
+    out.hit = false;
+    out.vx = out.vy = out.vz = 0;
+    f3 hit_pos = mk3(0, 0, 0);
+
+    while (total < max_steps) {
+        WalkResult c;
+        walk_level<true>(W, W.coarse_bits, W.cx, W.cy, W.cz, W.ctw, W.ctwh, start, dir, c, cnt.coarse_probes);
+        total += c.steps;
+        f3 local = mk3(c.point.x * W.ff, c.point.y * W.ff, c.point.z * W.ff);
+        hit_pos = local;
+        if (!(c.hit && !c.oob))
+            break;
+        const float hx = (float)c.hx, hy = (float)c.hy, hz = (float)c.hz;
+        if (last_x == hx && last_y == hy && last_z == hz)
+            break;  // :402-407
+        last_x = hx;
+        last_y = hy;
+        last_z = hz;
+        local = mk3(local.x - hx * W.ff, local.y - hy * W.ff, local.z - hz * W.ff);
+
+        uint32_t ci = tiled_index(c.hx, c.hy, c.hz, W.ctw, W.ctwh);
+        uint32_t slot = W.cell_meta[ci].x;
+        const uint32_t* bits = nullptr;
+        int bd = 0;
+        if (slot != kEmptySlot) {
+            bits = W.pool + (size_t)slot * W.brick_words;
+            bd = W.f;
+        }
+        cnt.brick_entries += 1;
+        WalkResult b;
+        walk_level<false>(W, bits, bd, bd, bd, W.ftw, W.ftwh, local, dir, b, cnt.fine_probes);
+        total += b.steps;
+        hit_pos = mk3(b.point.x + hx * W.ff, b.point.y + hy * W.ff, b.point.z + hz * W.ff);
+        if (b.hit) {
+            out.normal = (b.steps == 0) ? c.normal : b.normal;
+            out.vx = c.hx * W.f + b.hx;
+            out.vy = c.hy * W.f + b.hy;
+            out.vz = c.hz * W.f + b.hz;
+            out.hit = true;
+            break;
+        }
+        start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
+        if (b.oob) {
+            bool same = hx == (float)(int)start.x && hy == (float)(int)start.y && hz == (float)(int)start.z;
+            if (same) {
+                start.x = ulp_step(start.x, dir.x < 0);
+                start.y = ulp_step(start.y, dir.y < 0);
+                start.z = ulp_step(start.z, dir.z < 0);
+                same = hx == (float)(int)start.x && hy == (float)(int)start.y && hz == (float)(int)start.z;
+                if (same) {
+                    float gx = (float)c.ncx - start.x, gy = (float)c.ncy - start.y, gz = (float)c.ncz - start.z;
+                    float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
+                    if (mx < my && mx < mz)
+                        start.x += gx;
+                    else if (my < mx && my < mz)
+                        start.y += gy;
+                    else
+                        start.z += gz;
+                }
+            }
+        }
+    }
+    out.steps = total;
+    if (out.hit) {
+        out.pos = hit_pos;
+        if (total == 0) {
+            out.pos = mk3(start.x * W.ff, start.y * W.ff, start.z * W.ff);
+            out.normal = entry_n;
+        }
+    }
+}
+
+}  // namespace vxrt

@@ -1,0 +1,320 @@
+// vxrt_kernels.hip -- gfx950 kernels: per-pixel render (screenDispatch, VoxelRT/Renderer.cu:179-276),
+// batch trace (dispatch, VoxelRT/VolumeRaytracer.cu:95-117) and the strip de-interleave used after the
+// multi-GPU gather.  One wavefront (64 lanes) owns an 8x8 pixel tile; a 256-thread workgroup owns 16x16.
+#include "vxrt_kernels.hpp"
+
+namespace vxrt {
+
+// x^32 by five binary64 squarings rounded once to binary32: this build's definition of
+// powf(x, 32) at Renderer.cu:114 (libm powf differs in the last ulp between hosts and GPUs).
+__device__ __forceinline__ float pow32(float x)
+{
+    double p = (double)x;
+    p *= p;
+    p *= p;
+    p *= p;
+    p *= p;
+    p *= p;
+    return (float)p;
+}
+
+// cudaNoise::hash / randomFloat (cuda_noise.cuh:44-54,66-71)
+__device__ __forceinline__ uint32_t hash32(uint32_t s)
+{
+    s = (s + 0x7ed55d16u) + (s << 12);
+    s = (s ^ 0xc761c23cu) ^ (s >> 19);
+    s = (s + 0x165667b1u) + (s << 5);
+    s = (s + 0xd3a2646cu) ^ (s << 9);
+    s = (s + 0xfd7046c5u) + (s << 3);
+    s = (s ^ 0xb55a4f09u) ^ (s >> 16);
+    return s;
+}
+__device__ __forceinline__ float random_float(uint32_t s) { return (float)hash32(s) / 4294967296.0f; }
+
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v)
+{
+    unsigned long long t = v;
+    for (int off = 32; off > 0; off >>= 1)
+        t += __shfl_xor(t, off, 64);
+    return t;
+}
+
+struct PixelSink {
+    const RenderArgs& A;
+    int out_row;  // row inside the destination buffers (frame row, or packed shard row)
+    __device__ void put(int x, int y, f3 c) const
+    {
+        if ((uint32_t)x >= A.width || (uint32_t)y >= A.height)
+            return;
+        size_t i = (size_t)out_row * A.width + (size_t)x;
+        if (A.color_aov) {
+            A.color_aov[i * 3 + 0] = c.x;
+            A.color_aov[i * 3 + 1] = c.y;
+            A.color_aov[i * 3 + 2] = c.z;
+        }
+        // setPixelColor (Renderer.cu:72-87): clamp, *255, truncate; bytes b,g,r,a
+        float r = lo(hi(c.x, 0), 1), g = lo(hi(c.y, 0), 1), b = lo(hi(c.z, 0), 1);
+        uint32_t px = (uint32_t)(b * 255) | ((uint32_t)(g * 255) << 8) | ((uint32_t)(r * 255) << 16) | 0xFF000000u;
+        reinterpret_cast<uint32_t*>(A.fb)[i] = px;
+    }
+};
+
+// calculateColor (Renderer.cu:90-168) with the shadow ray (:102) and the sample count (:123) as run-time flags
+__device__ f3 shade(const RenderArgs& A, uint32_t tx, uint32_t ty, f3 cam, f3 normal, f3 position,
+                    RayCounters& cnt, uint32_t& n_shadow, uint32_t& n_bounce)
+{
+    const f3 L = A.light_dir;
+    f3 sray = unit3(L);
+    f3 spos = position + sray * 0.01f;
+    bool shadowed = false;
+    if (A.shadow) {
+        TraceResult t;
+        n_shadow += 1;
+        trace_direct(A.W, kMaxSteps, spos, sray, t, cnt);
+        shadowed = t.hit;
+    }
+    float l_dot = hi(dot3(normal, L), 0) * (float)(shadowed ? 0 : 1);
+    f3 diffuse = A.light_color * l_dot;
+    float up_dot = normal.x * 0.0f + normal.y * 1.0f + normal.z * 0.0f;
+    float t = (float)((double)up_dot * 0.5 + 0.5);
+    f3 color = diffuse + A.ambient * (0.25f + t * (1.0f - 0.25f));
+    if (!shadowed) {
+        f3 view = unit3(position - cam);
+        f3 refl = reflect3(L, normal);
+        float spec = pow32(hi(dot3(view, refl), 0));
+        color.x += spec * A.light_color.x;
+        color.y += spec * A.light_color.y;
+        color.z += spec * A.light_color.z;
+    }
+    if (l_dot == 0 || A.bounce_all_hits) {
+        const int samples = A.bounce_samples;
+        uint32_t seed = ty * A.width + tx;
+        float occl = 0.0f;
+        for (int i = 0; i < samples; ++i) {
+            uint32_t si = seed + (uint32_t)i * 1000u + (A.frame_number + 1u) * 1000u;
+            f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
+            sd = unit3(sd);
+            if (dot3(sd, normal) < 0)
+                sd = reflect3(sd, normal);
+            f3 sp = position + normal * 0.01f;
+            TraceResult tr;
+            n_bounce += 1;
+            trace_direct(A.W, 8, sp, sd, tr, cnt);
+            if (!tr.hit)
+                occl += 1.0f;
+        }
+        if (samples > 0)
+            occl /= (float)samples;
+        else
+            occl = 1.0f;
+        color = color * occl;
+    }
+    return color;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_render(RenderArgs A)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tx = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+
+    RayCounters cnt = {0, 0, 0};
+    uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
+
+    // launch row -> the reference launch's thread row `ty`
+    uint32_t ty = row;
+    const bool sharded = A.strip_count > 1;
+    if (sharded && !A.checkerboard) {
+        uint32_t strip = (row / (uint32_t)A.strip_rows) * (uint32_t)A.strip_count + (uint32_t)A.strip_index;
+        ty = strip * (uint32_t)A.strip_rows + row % (uint32_t)A.strip_rows;
+    }
+    bool live = row < A.launch_rows;
+    int x = (int)tx, y = (int)ty;
+    if (A.checkerboard) {  // Renderer.cu:186-194
+        y *= 2;
+        if ((x % 2) == 0)
+            y += 1;
+        if (A.frame_number % 2 == 0)
+            y += 1;
+    }
+    live = live && (uint32_t)x < A.width && (uint32_t)y < A.height;
+    if (live && sharded && ((uint32_t)y / (uint32_t)A.strip_rows) % (uint32_t)A.strip_count != (uint32_t)A.strip_index)
+        live = false;
+
+    if (live) {
+        const int Wd = (int)A.width, Hd = (int)A.height;
+        int out_row = y;
+        if (A.compact && sharded)
+            out_row = (int)((((uint32_t)y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
+                            (uint32_t)y % (uint32_t)A.strip_rows);
+        PixelSink sink{A, out_row};
+
+        float u = (float)x / (float)Wd, v = (float)y / (float)Hd;
+        f3 origin = A.origin;
+        f3 ray;
+        if (A.ortho) {  // getRayDirectionOrtho, Renderer.cu:61-70
+            ray = A.fwd;
+            origin = origin + ((A.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+            origin = origin + (A.up * (v * 2 - 1)) * A.ortho_y;
+        } else {  // getRayDirection, Renderer.cu:44-59
+            float su = u * 2 - 1, sv = v * 2 - 1;
+            ray.x = A.fwd.x + su * A.kx * A.right.x + sv * A.ky * A.up.x;
+            ray.y = A.fwd.y + su * A.kx * A.right.y + sv * A.ky * A.up.y;
+            ray.z = A.fwd.z + su * A.kx * A.right.z + sv * A.ky * A.up.z;
+            ray = unit3(ray);
+        }
+        TraceResult pr;
+        n_primary = 1;
+        trace_direct(A.W, kMaxSteps, origin, ray, pr, cnt);
+        f3 normal = mk3(-pr.normal.x, -pr.normal.y, -pr.normal.z);
+        int steps = pr.steps;
+        if (A.hit_aov)
+            A.hit_aov[(size_t)out_row * A.width + (size_t)x] =
+                pr.hit ? (long long)pr.vx + (long long)A.W.X * ((long long)pr.vy + (long long)A.W.Y * (long long)pr.vz)
+                       : -1ll;
+        if (pr.hit) {
+            n_hits = 1;
+            if (A.mode == 1) {  // DEBUG_VIEW quadrants, Renderer.cu:215-243
+                f3 dv = pr.pos - origin;
+                float dist = sqrtf(dot3(dv, dv));
+                const float wrap = (float)(1.0 + 1e-6);
+                f3 hp = mk3(fmodf(pr.pos.x / 128.0f, wrap), fmodf(pr.pos.y / 128.0f, wrap),
+                            fmodf(pr.pos.z / 128.0f, wrap));
+                if (x < (Wd >> 1) && y < (Hd >> 1))
+                    sink.put(x, y, normal);
+                else if (x >= (Wd >> 1) && y < (Hd >> 1))
+                    sink.put(x, y, hp);
+                else if (x < (Wd >> 1)) {
+                } else
+                    sink.put(x, y, mk3(dist * 0.01f, 0, 0));
+            } else {  // Renderer.cu:245-251
+                f3 c = shade(A, tx, ty, origin, normal, pr.pos, cnt, n_shadow, n_bounce);
+                c = mk3(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f));  // Tonemap, :170-177
+                c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
+                sink.put(x, y, c);
+            }
+        } else {
+            sink.put(x, y, ray);  // Renderer.cu:254-258
+        }
+        if (tx == (A.width >> 1) && ty == (A.height >> 1))  // crosshair on launch coordinates, :261-268
+            sink.put(x, y, mk3(10, 10, 10));
+        if (A.mode == 1 && x < (Wd >> 1) && y > (Hd >> 1))  // :270-275
+            sink.put(x, y, mk3((float)steps / 256.0f, 0, 0));
+    }
+
+    // one set of atomics per wavefront
+    unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_bounce),
+                       s3 = wave_sum(n_hits);
+    if (lane == 0 && A.stats) {
+        atomicAdd(&A.stats[kStatPrimary], s0);
+        atomicAdd(&A.stats[kStatShadow], s1);
+        atomicAdd(&A.stats[kStatBounce], s2);
+        atomicAdd(&A.stats[kStatPrimaryHits], s3);
+    }
+    if (STATS) {
+        unsigned long long p0 = wave_sum(cnt.coarse_probes), p1 = wave_sum(cnt.brick_entries),
+                           p2 = wave_sum(cnt.fine_probes);
+        if (lane == 0 && A.stats) {
+            atomicAdd(&A.stats[kStatCoarseProbes], p0);
+            atomicAdd(&A.stats[kStatBrickEntries], p1);
+            atomicAdd(&A.stats[kStatFineProbes], p2);
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_trace_batch(BatchArgs B)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    RayCounters cnt = {0, 0, 0};
+    uint32_t rays = 0, hits = 0;
+    if (i < B.n) {
+        f3 o = mk3(B.origins[3 * i], B.origins[3 * i + 1], B.origins[3 * i + 2]);
+        f3 d = mk3(B.dirs[3 * i], B.dirs[3 * i + 1], B.dirs[3 * i + 2]);
+        TraceResult t;
+        trace_direct(B.W, kMaxSteps, o, d, t, cnt);
+        rays = 1;
+        hits = t.hit ? 1 : 0;
+        f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);  // dispatch, VolumeRaytracer.cu:105-113
+        B.pos[3 * i] = p.x;
+        B.pos[3 * i + 1] = p.y;
+        B.pos[3 * i + 2] = p.z;
+        B.normal[3 * i] = t.normal.x;
+        B.normal[3 * i + 1] = t.normal.y;
+        B.normal[3 * i + 2] = t.normal.z;
+        B.steps[i] = t.steps;
+        if (B.hit)
+            B.hit[i] = t.hit ? 1 : 0;
+        if (B.voxel)
+            B.voxel[i] = t.hit ? (long long)t.vx + (long long)B.W.X * ((long long)t.vy + (long long)B.W.Y * (long long)t.vz)
+                               : -1ll;
+    }
+    if (STATS && B.stats) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long r = wave_sum(rays), h = wave_sum(hits), p0 = wave_sum(cnt.coarse_probes),
+                           p1 = wave_sum(cnt.brick_entries), p2 = wave_sum(cnt.fine_probes);
+        if (lane == 0) {
+            atomicAdd(&B.stats[kStatPrimary], r);
+            atomicAdd(&B.stats[kStatPrimaryHits], h);
+            atomicAdd(&B.stats[kStatCoarseProbes], p0);
+            atomicAdd(&B.stats[kStatBrickEntries], p1);
+            atomicAdd(&B.stats[kStatFineProbes], p2);
+        }
+    }
+}
+
+// packed shard buffers -> full frame: 16 bytes (4 pixels) per lane, rows are whole strips
+__global__ __launch_bounds__(256) void k_deinterleave(const uint4* __restrict__ shards, unsigned long long shard_stride_vec,
+                                                      uint4* __restrict__ fb, uint32_t width_vec, uint32_t height,
+                                                      uint32_t strip_rows, uint32_t strip_count)
+{
+    const unsigned long long total = (unsigned long long)width_vec * height;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        uint32_t y = (uint32_t)(i / width_vec), xv = (uint32_t)(i % width_vec);
+        uint32_t strip = y / strip_rows, shard = strip % strip_count;
+        uint32_t local_row = (strip / strip_count) * strip_rows + y % strip_rows;
+        fb[i] = shards[(unsigned long long)shard * shard_stride_vec + (unsigned long long)local_row * width_vec + xv];
+    }
+}
+
+void launch_render(const RenderArgs& A, bool stats, hipStream_t stream)
+{
+    dim3 block(256, 1, 1);
+    dim3 grid((A.width + 15) / 16, (A.launch_rows + 15) / 16, 1);
+    if (grid.x == 0 || grid.y == 0)
+        return;
+    if (stats)
+        hipLaunchKernelGGL(k_render<true>, grid, block, 0, stream, A);
+    else
+        hipLaunchKernelGGL(k_render<false>, grid, block, 0, stream, A);
+}
+
+void launch_trace_batch(const BatchArgs& B, bool stats, hipStream_t stream)
+{
+    if (B.n == 0)
+        return;
+    dim3 block(256, 1, 1);
+    dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
+    if (stats)
+        hipLaunchKernelGGL(k_trace_batch<true>, grid, block, 0, stream, B);
+    else
+        hipLaunchKernelGGL(k_trace_batch<false>, grid, block, 0, stream, B);
+}
+
+void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
+                         uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream)
+{
+    uint32_t width_vec = width / 4;  // caller guarantees width % 4 == 0
+    unsigned long long total = (unsigned long long)width_vec * height;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (blocks > 2048)
+        blocks = 2048;
+    if (blocks == 0)
+        return;
+    hipLaunchKernelGGL(k_deinterleave, dim3(blocks), dim3(256), 0, stream, (const uint4*)shards, shard_stride_bytes / 16,
+                       (uint4*)fb, width_vec, height, strip_rows, strip_count);
+}
+
+}  // namespace vxrt

@@ -1,0 +1,52 @@
+// vxrt_kernels.hpp -- kernel argument blocks shared by the kernels and the host API.
+#pragma once
+
+#include "vxrt_device.hpp"
+
+namespace vxrt {
+
+// indices into the per-context device counter block
+enum StatSlot {
+    kStatPrimary = 0,
+    kStatShadow,
+    kStatBounce,
+    kStatPrimaryHits,
+    kStatCoarseProbes,
+    kStatBrickEntries,
+    kStatFineProbes,
+    kStatCount
+};
+
+// Everything screenDispatch read from dFrameInfo / g_env / its arguments (Renderer.cu:7-24,89,179-181),
+// passed by value with the launch: no per-frame symbol copy.
+struct RenderArgs {
+    WorldView W;
+    uint32_t width, height;
+    uint32_t frame_number;
+    uint32_t launch_rows;  // rows of the launch grid (height, height/2 with checkerboard, or the shard's rows)
+    float kx, ky;          // tan(fov/2)*aspect, tan(fov/2), evaluated on the host (Renderer.cu:50-52)
+    float ortho_x, ortho_y, ratio;
+    f3 origin, fwd, up, right;
+    f3 light_dir, light_color, ambient;
+    int mode, checkerboard, shadow, bounce_samples, bounce_all_hits, ortho;
+    int strip_rows, strip_count, strip_index, compact;
+    uint8_t* fb;
+    float* color_aov;
+    long long* hit_aov;
+    unsigned long long* stats;
+};
+
+struct BatchArgs {
+    WorldView W;
+    const float* origins;
+    const float* dirs;
+    unsigned long long n;
+    float* pos;
+    float* normal;
+    int* steps;
+    uint8_t* hit;
+    long long* voxel;
+    unsigned long long* stats;
+};
+
+}  // namespace vxrt

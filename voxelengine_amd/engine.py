@@ -1,0 +1,204 @@
+"""Host-side mirror of the reference's VoxelRT interface over the C ABI (include/vxrt.h).
+
+Reference surface (VoxelRT/VolumeRaytracer.cuh:291-377, VoxelRT/Renderer.cuh:39-55):
+``VoxelRaytracer3D`` {UploadVoxelBuffer, UploadVoxelBufferDatas, UploadVoxelBufferDataBounds, SetFactor,
+Raytrace} and ``Graphics`` {GetDirections, SetEnvironment, SetFOV, SetOrthoWindowSize, RenderScreen}.
+Here one :class:`Context` per GPU carries what the reference keeps in process globals, so eight GPUs can
+run from eight ranks.  PyTorch only supplies device memory and streams; every pixel and ray is produced by
+the HIP kernels in ``csrc/``.  There is no CPU fallback: without libvxrt.so and a GPU these calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as N
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def GetDirections(euler):
+    """Graphics::GetDirections (VoxelRT/Renderer.cu:27-42). Host math only."""
+    f, u, r = (C.c_float * 3)(), (C.c_float * 3)(), (C.c_float * 3)()
+    N.load().vxrt_get_directions(_f3(euler), f, u, r)
+    return (np.array(f[:], np.float32), np.array(u[:], np.float32), np.array(r[:], np.float32))
+
+
+def compact_rows(height: int, strip_rows: int, strip_count: int, strip_index: int) -> int:
+    return int(N.load().vxrt_compact_rows(height, strip_rows, strip_count, strip_index))
+
+
+@dataclass
+class RenderOptions:
+    """Run-time forms of the reference's compile-time switches (VoxelRT/Renderer.cu:4-5,102,123)."""
+    mode: int = N.MODE_SHADED
+    checkerboard: bool = False
+    shadow: bool = False
+    bounce_samples: int = 0
+    bounce_all_hits: bool = False
+    ortho: bool = False
+    frame_number: int = -1          # < 0: context counter with the reference's post-copy increment
+    strip_rows: int = 16
+    strip_count: int = 1
+    strip_index: int = 0
+    compact: bool = False
+    collect_stats: bool = False
+    extra: dict = field(default_factory=dict)
+
+
+class Context:
+    """One MI355X: resident brickmap + camera/lighting state + launches."""
+
+    def __init__(self, device: int = 0):
+        self._L = N.load()
+        h = C.c_void_p()
+        N.check(self._L.vxrt_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.vxrt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- world ----------------------------------------------------------------------------------
+    def upload_world(self, factor: int, cdims, coarse_bits, brick_slot, bounds, pool) -> None:
+        """UploadVoxelBuffer + UploadVoxelBufferDatas + UploadVoxelBufferDataBounds + SetFactor
+        (VoxelRT/VolumeRaytracer.cu:527-572) with the tables as flat host arrays."""
+        cb = np.ascontiguousarray(coarse_bits, np.uint32)
+        bs = np.ascontiguousarray(brick_slot, np.uint32)
+        bd = np.ascontiguousarray(bounds, np.float32)
+        pl = np.ascontiguousarray(pool, np.uint32)
+        d = N.WorldDesc()
+        d.struct_size = C.sizeof(N.WorldDesc)
+        d.factor = factor
+        d.cdims = (C.c_int32 * 3)(*[int(c) for c in cdims])
+        d.nslots = pl.size // (factor ** 3 // 32)
+        d.coarse_bits, d.brick_slot, d.bounds = cb.ctypes.data, bs.ctypes.data, bd.ctypes.data
+        d.pool = pl.ctypes.data if pl.size else None
+        N.check(self._L.vxrt_upload_world(self._h, C.byref(d)))
+
+    def build_world(self, generator: int, X: int, Y: int, Z: int, factor: int) -> "N.WorldInfo":
+        """CreateVoxels + GenerateLowresVoxelBuffer on the device, brick by brick."""
+        N.check(self._L.vxrt_build_world_procedural(self._h, generator, X, Y, Z, factor))
+        return self.world_info()
+
+    def world_info(self) -> "N.WorldInfo":
+        info = N.WorldInfo()
+        N.check(self._L.vxrt_world_info_get(self._h, C.byref(info)))
+        return info
+
+    def download_world(self, with_pool: bool = True):
+        info = self.world_info()
+        n = int(info.ncells)
+        cb = np.empty((n + 31) // 32, np.uint32)
+        bs = np.empty(n, np.uint32)
+        bd = np.empty((n, 6), np.float32)
+        bw = info.factor ** 3 // 32
+        pl = np.empty(int(info.nslots) * bw, np.uint32) if with_pool else None
+        N.check(self._L.vxrt_download_world(self._h, cb.ctypes.data, bs.ctypes.data, bd.ctypes.data,
+                                            pl.ctypes.data if (with_pool and pl.size) else None))
+        return dict(factor=int(info.factor), cdims=tuple(info.cdims), coarse_bits=cb, brick_slot=bs, bounds=bd,
+                    pool=pl)
+
+    # ---- state ----------------------------------------------------------------------------------
+    def SetEnvironment(self, light_dir, light_color, ambient) -> None:
+        N.check(self._L.vxrt_set_environment(self._h, _f3(light_dir), _f3(light_color), _f3(ambient)))
+
+    def SetFOV(self, fov: float) -> None:
+        N.check(self._L.vxrt_set_fov(self._h, float(fov)))
+
+    def SetOrthoWindowSize(self, sx: float, sy: float) -> None:
+        N.check(self._L.vxrt_set_ortho_window_size(self._h, float(sx), float(sy)))
+
+    # ---- per frame -------------------------------------------------------------------------------
+    def RenderScreen(self, width: int, height: int, d_fb, origin, fwd, up, right, opts: RenderOptions | None = None,
+                     color_aov=None, hit_aov=None, stream: int | None = None) -> None:
+        """Graphics::RenderScreen (VoxelRT/Renderer.cu:305-328).  ``d_fb``/AOVs: torch CUDA tensors or raw
+        device addresses.  Asynchronous on ``stream`` (default: torch's current stream)."""
+        o = opts or RenderOptions()
+        fl = N.RenderFlags()
+        self._L.vxrt_render_flags_default(C.byref(fl))
+        fl.mode, fl.checkerboard, fl.shadow = int(o.mode), int(o.checkerboard), int(o.shadow)
+        fl.bounce_samples, fl.bounce_all_hits, fl.ortho = int(o.bounce_samples), int(o.bounce_all_hits), int(o.ortho)
+        fl.frame_number = int(o.frame_number)
+        fl.strip_rows, fl.strip_count, fl.strip_index = int(o.strip_rows), int(o.strip_count), int(o.strip_index)
+        fl.compact, fl.collect_stats = int(o.compact), int(o.collect_stats)
+        fl.d_color_aov = _ptr(color_aov)
+        fl.d_hit_aov = _ptr(hit_aov)
+        fl.stream = _stream(stream)
+        N.check(self._L.vxrt_render(self._h, width, height, _ptr(d_fb), _f3(origin), _f3(fwd), _f3(up), _f3(right),
+                                    C.byref(fl)))
+
+    def frame_stats(self) -> "N.FrameStats":
+        st = N.FrameStats()
+        N.check(self._L.vxrt_frame_stats_get(self._h, C.byref(st)))
+        return st
+
+    def deinterleave_strips(self, width, height, strip_rows, strip_count, d_shards, shard_stride_bytes, d_fb,
+                            stream: int | None = None) -> None:
+        N.check(self._L.vxrt_deinterleave_strips(self._h, width, height, strip_rows, strip_count, _ptr(d_shards),
+                                                 int(shard_stride_bytes), _ptr(d_fb), _stream(stream)))
+
+    # ---- batch -----------------------------------------------------------------------------------
+    def Raytrace(self, origins, dirs, want_stats: bool = False):
+        """VoxelRaytracer3D::Raytrace (VoxelRT/VolumeRaytracer.cu:574-618) on host arrays: copy in, trace,
+        copy out.  Returns the reference's fields (hitPoint=+inf on a miss, normal, steps, valid, distance)
+        plus this build's hit voxel index."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        pos = np.empty((n, 3), np.float32)
+        nrm = np.empty((n, 3), np.float32)
+        steps = np.empty(n, np.int32)
+        hit = np.empty(n, np.uint8)
+        vox = np.empty(n, np.int64)
+        st = N.FrameStats()
+        N.check(self._L.vxrt_trace_batch_host(self._h, o.ctypes.data, d.ctypes.data, n, pos.ctypes.data,
+                                              nrm.ctypes.data, steps.ctypes.data, hit.ctypes.data, vox.ctypes.data,
+                                              C.byref(st) if want_stats else None))
+        valid = np.isfinite(pos).all(axis=1)
+        with np.errstate(invalid="ignore"):
+            dist = np.sqrt(((o - pos) ** 2).sum(axis=1, dtype=np.float32))
+        return dict(hitPoint=pos, normal=nrm, steps=steps, valid=valid, distance=dist, hit=hit, voxel=vox,
+                    stats=st if want_stats else None)
+
+    def trace_batch_device(self, d_origins, d_dirs, n, d_pos, d_normal, d_steps, d_hit=None, d_voxel=None,
+                           want_stats=False, stream: int | None = None):
+        st = N.FrameStats()
+        N.check(self._L.vxrt_trace_batch(self._h, _ptr(d_origins), _ptr(d_dirs), int(n), _ptr(d_pos), _ptr(d_normal),
+                                         _ptr(d_steps), _ptr(d_hit), _ptr(d_voxel),
+                                         C.byref(st) if want_stats else None, _stream(stream)))
+        return st if want_stats else None
+
+    def synchronize(self) -> None:
+        N.check(self._L.vxrt_synchronize(self._h))
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        if not x.is_cuda:
+            raise ValueError("device tensor expected")
+        return x.data_ptr()
+    raise TypeError(f"cannot take a device pointer from {type(x)}")
+
+
+def _stream(s):
+    if s is not None:
+        return s
+    import torch
+    return torch.cuda.current_stream().cuda_stream
