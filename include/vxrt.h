@@ -45,6 +45,10 @@ int vxrt_destroy(vxrt_ctx *ctx);
 /* message of the last failing call on this thread (never NULL) */
 const char *vxrt_last_error(void);
 int vxrt_synchronize(vxrt_ctx *ctx);
+/* kernel implementation used by vxrt_render / vxrt_trace_batch: 0 = wave-level state machine (default),
+ * 1 = straightforward per-lane loops.  Both give identical results; 1 exists for A/B timing and as an
+ * on-device cross-check. */
+int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 
 /* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,
  * ::UploadVoxelBufferDatas, ::UploadVoxelBufferDataBounds and ::SetFactor

@@ -66,6 +66,24 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
+def test_straightforward_kernel_variant_agrees(eng, vxo):
+    """Kernel variant 1 (per-lane loops, kept for A/B timing) gives the same bits as the default wave-level
+    state machine and as the oracle."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    o, d = helpers.mixed_rays(w.dims, 20000, 21)
+    cpu = w.trace_batch(o, d)
+    try:
+        ctx.set_kernel_variant(1)
+        _assert_batch_equal(ctx.Raytrace(o, d), cpu)
+        res = _render_both(eng, vxo, w, 160, 96, "A", frame_number=5, shadow=1, bounce_samples=2)
+        _assert_frame_equal(*res)
+    finally:
+        ctx.set_kernel_variant(0)
+    _assert_batch_equal(ctx.Raytrace(o, d), cpu)
+
+
 def test_known_answer_rays_on_gpu(eng, vxo):
     """The hand-derived cases of tests/test_oracle_kat.py, through the HIP path."""
     vx, ctx, _ = eng

@@ -1,0 +1,51 @@
+// Debug harness: runs vxrt::trace_wave (one lane) and vxrt::trace_direct on the host against the C oracle.
+// build: g++ -O1 -g -std=c++17 -ffp-contract=off -Itools/hoststub -Ioracle tools/host_wave_check.cpp oracle/vxo_*.c -lm -lpthread
+#include "../voxelengine_amd/csrc/vxrt_wave.hpp"
+extern "C" {
+#include "vxo.h"
+}
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+using namespace vxrt;
+int main(int argc, char** argv)
+{
+    int f = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 64;
+    double dens = argc > 3 ? atof(argv[3]) : 0.01;
+    int n = argc > 4 ? atoi(argv[4]) : 30000;
+    std::vector<uint32_t> dense((size_t)S * S * S / 32, 0);
+    srand(1);
+    for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
+        if (rand() / (double)RAND_MAX < dens) { uint64_t i = vxo_sample_index64(x, y, z, S, S); dense[i >> 5] |= 1u << (i & 31); }
+    vxo_world* w = vxo_build_brickmap(dense.data(), S, S, S, f);
+    std::vector<uint2> meta(w->ncells);
+    for (uint64_t i = 0; i < w->ncells; ++i) {
+        uint32_t p = 0;
+        if (w->brick_slot[i] != VXO_EMPTY_SLOT) for (int k = 0; k < 6; ++k) p |= (uint32_t)(int)w->bounds[i * 6 + k] << (5 * k);
+        meta[i] = make_uint2(w->brick_slot[i], p);
+    }
+    WorldView W{};
+    W.coarse_bits = w->coarse_bits; W.cell_meta = meta.data(); W.pool = w->pool;
+    W.cx = w->cdims[0]; W.cy = w->cdims[1]; W.cz = w->cdims[2]; W.ctw = W.cx / 8; W.ctwh = W.ctw * (W.cy / 8);
+    W.f = f; W.ftw = f / 8; W.ftwh = W.ftw * W.ftw; W.brick_words = f * f * f / 32; W.ff = (float)f; W.inv_f = 1.0f / f;
+    W.wmax_x = (float)((double)W.cx - 1e-6); W.wmax_y = (float)((double)W.cy - 1e-6); W.wmax_z = (float)((double)W.cz - 1e-6);
+    W.X = S; W.Y = S;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        float o[3], d[3];
+        for (int a = 0; a < 3; ++a) { o[a] = (rand() / (float)RAND_MAX) * (i % 3 ? S : 3 * S) - (i % 3 ? 0 : S); d[a] = rand() / (float)RAND_MAX * 2 - 1; }
+        if (i % 7 == 0) d[i % 3] = 0;
+        if (i % 11 == 0) { o[0] = floorf(o[0]); o[1] = floorf(o[1]); }
+        int steps; float nn[3], pp[3] = {0, 0, 0}; int vox[3] = {0, 0, 0}; vxo_ray_stats st{};
+        int h = vxo_raytrace(w, 2048, o, d, &steps, nn, pp, vox, &st);
+        TraceResult t; RayCounters c{0, 0, 0};
+        trace_wave<true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t, c);
+        bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries && c.fine_probes == st.fine_probes;
+        if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
+        if (!ok && bad++ < 5)
+            printf("ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g) cpu hit=%d steps=%d probes=%llu/%llu/%llu | wave hit=%d steps=%d probes=%u/%u/%u\n", i, o[0], o[1], o[2], d[0], d[1], d[2], h, steps,
+                   (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries, (unsigned long long)st.fine_probes, t.hit, t.steps, c.coarse_probes, c.brick_entries, c.fine_probes);
+    }
+    printf("mismatches %d of %d\n", bad, n);
+    return bad != 0;
+}

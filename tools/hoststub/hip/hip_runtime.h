@@ -1,0 +1,22 @@
+// Host stand-in for the few HIP device builtins vxrt_device.hpp / vxrt_wave.hpp use, so the traversal code can be
+// compiled for the CPU with ONE lane per "wave" and stepped in a debugger / compared with the oracle.
+// Debug tooling only (tools/host_wave_check.cpp); never part of the product build.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <algorithm>
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __restrict__
+#define __global__
+#define __launch_bounds__(x)
+struct uint2 { uint32_t x, y; };
+static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+using std::min;
+using std::max;

@@ -12,8 +12,8 @@
 #include <vector>
 
 namespace vxrt {
-void launch_render(const RenderArgs& A, bool stats, hipStream_t stream);
-void launch_trace_batch(const BatchArgs& B, bool stats, hipStream_t stream);
+void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
+void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
                          uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream);
 int build_world_on_device(struct ::vxrt_ctx* ctx, int generator, int X, int Y, int Z, int factor);
@@ -50,6 +50,7 @@ struct vxrt_ctx {
     float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
     float ortho[2] = {10.0f, 10.0f};
     uint32_t frame_counter = 0;
+    int kernel_variant = 0;          // 0 = wave state machine, 1 = straightforward loops
     unsigned long long* d_stats = nullptr;
 };
 
@@ -173,6 +174,14 @@ int vxrt_destroy(vxrt_ctx* c)
     vxrt::free_world(c);
     if (c->d_stats) (void)hipFree(c->d_stats);
     delete c;
+    return VXRT_OK;
+}
+
+int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
+{
+    if (!c || variant < 0 || variant > 1)
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave) or 1 (direct)");
+    c->kernel_variant = variant;
     return VXRT_OK;
 }
 
@@ -426,7 +435,7 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
     A.color_aov = fl->d_color_aov;
     A.hit_aov = (long long*)fl->d_hit_aov;
     A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
-    vxrt::launch_render(A, fl->collect_stats != 0, stream);
+    vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
     VX_HIP(hipGetLastError());
     return VXRT_OK;
 }
@@ -490,7 +499,7 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
         VX_HIP(hipDeviceSynchronize());
         VX_HIP(hipMemset(c->d_stats, 0, vxrt::kStatCount * sizeof(unsigned long long)));
     }
-    vxrt::launch_trace_batch(B, stats != nullptr, stream);
+    vxrt::launch_trace_batch(B, stats != nullptr, c->kernel_variant, stream);
     VX_HIP(hipGetLastError());
     if (stats) {
         VX_HIP(hipStreamSynchronize(stream));

@@ -2,6 +2,7 @@
 // batch trace (dispatch, VoxelRT/VolumeRaytracer.cu:95-117) and the strip de-interleave used after the
 // multi-GPU gather.  One wavefront (64 lanes) owns an 8x8 pixel tile; a 256-thread workgroup owns 16x16.
 #include "vxrt_kernels.hpp"
+#include "vxrt_wave.hpp"
 
 namespace vxrt {
 
@@ -279,28 +280,255 @@ __global__ __launch_bounds__(256) void k_deinterleave(const uint4* __restrict__ 
     }
 }
 
-void launch_render(const RenderArgs& A, bool stats, hipStream_t stream)
+// ---- wave-level kernels (vxrt_wave.hpp): every trace is entered by the whole wavefront at a converged point
+// with an `active` predicate, so the ballots inside see all 64 lanes ---------------------------------------
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t tx = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
+    const uint32_t row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+
+    RayCounters cnt = {0, 0, 0};
+    uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
+
+    uint32_t ty = row;
+    const bool sharded = A.strip_count > 1;
+    if (sharded && !A.checkerboard) {
+        uint32_t strip = (row / (uint32_t)A.strip_rows) * (uint32_t)A.strip_count + (uint32_t)A.strip_index;
+        ty = strip * (uint32_t)A.strip_rows + row % (uint32_t)A.strip_rows;
+    }
+    bool live = row < A.launch_rows;
+    int x = (int)tx, y = (int)ty;
+    if (A.checkerboard) {  // Renderer.cu:186-194
+        y *= 2;
+        if ((x % 2) == 0)
+            y += 1;
+        if (A.frame_number % 2 == 0)
+            y += 1;
+    }
+    live = live && (uint32_t)x < A.width && (uint32_t)y < A.height;
+    if (live && sharded && ((uint32_t)y / (uint32_t)A.strip_rows) % (uint32_t)A.strip_count != (uint32_t)A.strip_index)
+        live = false;
+
+    const int Wd = (int)A.width, Hd = (int)A.height;
+    int out_row = y;
+    if (A.compact && sharded)
+        out_row = (int)((((uint32_t)y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
+                        (uint32_t)y % (uint32_t)A.strip_rows);
+    PixelSink sink{A, out_row};
+
+    // camera ray (getRayDirection / getRayDirectionOrtho, Renderer.cu:44-70)
+    const float u = (float)x / (float)Wd, v = (float)y / (float)Hd;
+    f3 origin = A.origin;
+    f3 ray;
+    if (A.ortho) {
+        ray = A.fwd;
+        origin = origin + ((A.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+        origin = origin + (A.up * (v * 2 - 1)) * A.ortho_y;
+    } else {
+        float su = u * 2 - 1, sv = v * 2 - 1;
+        ray.x = A.fwd.x + su * A.kx * A.right.x + sv * A.ky * A.up.x;
+        ray.y = A.fwd.y + su * A.kx * A.right.y + sv * A.ky * A.up.y;
+        ray.z = A.fwd.z + su * A.kx * A.right.z + sv * A.ky * A.up.z;
+        ray = unit3(ray);
+    }
+
+    TraceResult pr;
+    trace_wave<STATS>(A.W, kMaxSteps, live, origin, ray, pr, cnt);
+    n_primary = live ? 1u : 0u;
+    const bool hit = live && pr.hit;
+    n_hits = hit ? 1u : 0u;
+    const f3 normal = mk3(-pr.normal.x, -pr.normal.y, -pr.normal.z);
+    const f3 position = pr.pos;
+    const bool lit = hit && A.mode == 0;  // lanes that run calculateColor (Renderer.cu:90-168)
+
+    // shadow ray (Renderer.cu:97-102), entered by the whole wave
+    const f3 L = A.light_dir;
+    const f3 sray = unit3(L);
+    bool shadowed = false;
+    if (A.shadow) {
+        TraceResult ts;
+        trace_wave<STATS>(A.W, kMaxSteps, lit, position + sray * 0.01f, sray, ts, cnt);
+        shadowed = lit && ts.hit;
+        n_shadow = lit ? 1u : 0u;
+    }
+    const float l_dot = hi(dot3(normal, L), 0) * (float)(shadowed ? 0 : 1);
+    f3 color = mk3(0, 0, 0);
+    {
+        f3 diffuse = A.light_color * l_dot;
+        float up_dot = normal.x * 0.0f + normal.y * 1.0f + normal.z * 0.0f;
+        float t = (float)((double)up_dot * 0.5 + 0.5);
+        color = diffuse + A.ambient * (0.25f + t * (1.0f - 0.25f));
+        if (!shadowed) {
+            f3 view = unit3(position - origin);
+            f3 refl = reflect3(L, normal);
+            float spec = pow32(hi(dot3(view, refl), 0));
+            color.x += spec * A.light_color.x;
+            color.y += spec * A.light_color.y;
+            color.z += spec * A.light_color.z;
+        }
+    }
+    // occlusion / bounce samples (Renderer.cu:121-165)
+    const bool gate = lit && (l_dot == 0 || A.bounce_all_hits);
+    {
+        const int samples = A.bounce_samples;
+        const uint32_t seed = ty * A.width + tx;
+        float occl = 0.0f;
+        for (int i = 0; i < samples; ++i) {
+            uint32_t si = seed + (uint32_t)i * 1000u + (A.frame_number + 1u) * 1000u;
+            f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
+            sd = unit3(sd);
+            if (dot3(sd, normal) < 0)
+                sd = reflect3(sd, normal);
+            TraceResult tb;
+            trace_wave<STATS>(A.W, 8, gate, position + normal * 0.01f, sd, tb, cnt);
+            if (gate) {
+                n_bounce += 1;
+                if (!tb.hit)
+                    occl += 1.0f;
+            }
+        }
+        if (gate) {
+            if (samples > 0)
+                occl /= (float)samples;
+            else
+                occl = 1.0f;
+            color = color * occl;
+        }
+    }
+
+    if (live) {
+        if (A.hit_aov)
+            A.hit_aov[(size_t)out_row * A.width + (size_t)x] =
+                pr.hit ? (long long)pr.vx + (long long)A.W.X * ((long long)pr.vy + (long long)A.W.Y * (long long)pr.vz)
+                       : -1ll;
+        if (pr.hit) {
+            if (A.mode == 1) {  // DEBUG_VIEW quadrants, Renderer.cu:215-243
+                f3 dv = pr.pos - origin;
+                float dist = sqrtf(dot3(dv, dv));
+                const float wrap = (float)(1.0 + 1e-6);
+                f3 hp = mk3(fmodf(pr.pos.x / 128.0f, wrap), fmodf(pr.pos.y / 128.0f, wrap),
+                            fmodf(pr.pos.z / 128.0f, wrap));
+                if (x < (Wd >> 1) && y < (Hd >> 1))
+                    sink.put(x, y, normal);
+                else if (x >= (Wd >> 1) && y < (Hd >> 1))
+                    sink.put(x, y, hp);
+                else if (x < (Wd >> 1)) {
+                } else
+                    sink.put(x, y, mk3(dist * 0.01f, 0, 0));
+            } else {
+                f3 c = mk3(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));  // Tonemap
+                c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
+                sink.put(x, y, c);
+            }
+        } else {
+            sink.put(x, y, ray);
+        }
+        if (tx == (A.width >> 1) && ty == (A.height >> 1))
+            sink.put(x, y, mk3(10, 10, 10));
+        if (A.mode == 1 && x < (Wd >> 1) && y > (Hd >> 1))
+            sink.put(x, y, mk3((float)pr.steps / 256.0f, 0, 0));
+    }
+
+    unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_bounce),
+                       s3 = wave_sum(n_hits);
+    if (lane == 0 && A.stats) {
+        atomicAdd(&A.stats[kStatPrimary], s0);
+        atomicAdd(&A.stats[kStatShadow], s1);
+        atomicAdd(&A.stats[kStatBounce], s2);
+        atomicAdd(&A.stats[kStatPrimaryHits], s3);
+    }
+    if (STATS) {
+        unsigned long long p0 = wave_sum(cnt.coarse_probes), p1 = wave_sum(cnt.brick_entries),
+                           p2 = wave_sum(cnt.fine_probes);
+        if (lane == 0 && A.stats) {
+            atomicAdd(&A.stats[kStatCoarseProbes], p0);
+            atomicAdd(&A.stats[kStatBrickEntries], p1);
+            atomicAdd(&A.stats[kStatFineProbes], p2);
+        }
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    RayCounters cnt = {0, 0, 0};
+    const bool live = i < B.n;
+    const unsigned long long j = live ? i : 0ull;
+    f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
+    f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
+    TraceResult t;
+    trace_wave<STATS>(B.W, kMaxSteps, live, o, d, t, cnt);
+    if (live) {
+        f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
+        B.pos[3 * i] = p.x;
+        B.pos[3 * i + 1] = p.y;
+        B.pos[3 * i + 2] = p.z;
+        B.normal[3 * i] = t.normal.x;
+        B.normal[3 * i + 1] = t.normal.y;
+        B.normal[3 * i + 2] = t.normal.z;
+        B.steps[i] = t.steps;
+        if (B.hit)
+            B.hit[i] = t.hit ? 1 : 0;
+        if (B.voxel)
+            B.voxel[i] = t.hit ? (long long)t.vx + (long long)B.W.X * ((long long)t.vy + (long long)B.W.Y * (long long)t.vz)
+                               : -1ll;
+    }
+    if (STATS && B.stats) {
+        const int lane = threadIdx.x & 63;
+        unsigned long long r = wave_sum(live ? 1u : 0u), h = wave_sum(live && t.hit ? 1u : 0u),
+                           p0 = wave_sum(cnt.coarse_probes), p1 = wave_sum(cnt.brick_entries),
+                           p2 = wave_sum(cnt.fine_probes);
+        if (lane == 0) {
+            atomicAdd(&B.stats[kStatPrimary], r);
+            atomicAdd(&B.stats[kStatPrimaryHits], h);
+            atomicAdd(&B.stats[kStatCoarseProbes], p0);
+            atomicAdd(&B.stats[kStatBrickEntries], p1);
+            atomicAdd(&B.stats[kStatFineProbes], p2);
+        }
+    }
+}
+
+// variant 0 = wave state machine (product default), 1 = straightforward per-lane loops (A/B and cross-check)
+void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
 {
     dim3 block(256, 1, 1);
     dim3 grid((A.width + 15) / 16, (A.launch_rows + 15) / 16, 1);
     if (grid.x == 0 || grid.y == 0)
         return;
-    if (stats)
-        hipLaunchKernelGGL(k_render<true>, grid, block, 0, stream, A);
-    else
-        hipLaunchKernelGGL(k_render<false>, grid, block, 0, stream, A);
+    if (variant == 1) {
+        if (stats)
+            hipLaunchKernelGGL(k_render<true>, grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL(k_render<false>, grid, block, 0, stream, A);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL(k_render_wave<true>, grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL(k_render_wave<false>, grid, block, 0, stream, A);
+    }
 }
 
-void launch_trace_batch(const BatchArgs& B, bool stats, hipStream_t stream)
+void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream)
 {
     if (B.n == 0)
         return;
     dim3 block(256, 1, 1);
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
-    if (stats)
-        hipLaunchKernelGGL(k_trace_batch<true>, grid, block, 0, stream, B);
-    else
-        hipLaunchKernelGGL(k_trace_batch<false>, grid, block, 0, stream, B);
+    if (variant == 1) {
+        if (stats)
+            hipLaunchKernelGGL(k_trace_batch<true>, grid, block, 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_trace_batch<false>, grid, block, 0, stream, B);
+    } else {
+        if (stats)
+            hipLaunchKernelGGL(k_trace_batch_wave<true>, grid, block, 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_trace_batch_wave<false>, grid, block, 0, stream, B);
+    }
 }
 
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,

@@ -181,6 +181,10 @@ class Context:
                                          C.byref(st) if want_stats else None, _stream(stream)))
         return st if want_stats else None
 
+    def set_kernel_variant(self, variant: int) -> None:
+        """0 = wave-level state machine (default), 1 = straightforward per-lane loops (A/B, cross-check)."""
+        N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
+
     def synchronize(self) -> None:
         N.check(self._L.vxrt_synchronize(self._h))
 
