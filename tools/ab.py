@@ -4,7 +4,9 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+import os
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import voxelengine_amd as vx  # noqa: E402
 

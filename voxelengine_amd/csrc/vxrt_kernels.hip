@@ -4,6 +4,8 @@
 #include "vxrt_kernels.hpp"
 #include "vxrt_wave.hpp"
 
+#include <cstdlib>
+
 namespace vxrt {
 
 // x^32 by five binary64 squarings rounded once to binary32: this build's definition of
@@ -117,8 +119,9 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void k_render(RenderArgs A)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tx = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const uint32_t row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t tile = blockDim.x == 64u ? 8u : 16u;  // one 8x8 wave tile per workgroup, or 2x2 of them
+    const uint32_t tx = blockIdx.x * tile + (wave & 1) * 8 + (lane & 7);
+    const uint32_t row = blockIdx.y * tile + (wave >> 1) * 8 + (lane >> 3);
 
     RayCounters cnt = {0, 0, 0};
     uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
@@ -287,8 +290,9 @@ template <bool STATS>
 __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tx = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const uint32_t row = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const uint32_t tile = blockDim.x == 64u ? 8u : 16u;  // one 8x8 wave tile per workgroup, or 2x2 of them
+    const uint32_t tx = blockIdx.x * tile + (wave & 1) * 8 + (lane & 7);
+    const uint32_t row = blockIdx.y * tile + (wave >> 1) * 8 + (lane >> 3);
 
     RayCounters cnt = {0, 0, 0};
     uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
@@ -495,20 +499,23 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 // variant 0 = wave state machine (product default), 1 = straightforward per-lane loops (A/B and cross-check)
 void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
 {
-    dim3 block(256, 1, 1);
-    dim3 grid((A.width + 15) / 16, (A.launch_rows + 15) / 16, 1);
+    static const int threads = getenv("VXRT_BLOCK") ? atoi(getenv("VXRT_BLOCK")) : 256;
+    const unsigned tile = threads == 64 ? 8u : 16u;
+    dim3 block(threads == 64 ? 64 : 256, 1, 1);
+    dim3 grid((A.width + tile - 1) / tile, (A.launch_rows + tile - 1) / tile, 1);
     if (grid.x == 0 || grid.y == 0)
         return;
+    static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
     if (variant == 1) {
         if (stats)
-            hipLaunchKernelGGL(k_render<true>, grid, block, 0, stream, A);
+            hipLaunchKernelGGL(k_render<true>, grid, block, lds, stream, A);
         else
-            hipLaunchKernelGGL(k_render<false>, grid, block, 0, stream, A);
+            hipLaunchKernelGGL(k_render<false>, grid, block, lds, stream, A);
     } else {
         if (stats)
-            hipLaunchKernelGGL(k_render_wave<true>, grid, block, 0, stream, A);
+            hipLaunchKernelGGL(k_render_wave<true>, grid, block, lds, stream, A);
         else
-            hipLaunchKernelGGL(k_render_wave<false>, grid, block, 0, stream, A);
+            hipLaunchKernelGGL(k_render_wave<false>, grid, block, lds, stream, A);
     }
 }
 

@@ -1,21 +1,24 @@
 // vxrt_wave.hpp -- the two-level brickmap DDA as a flat, wave-level state machine for gfx950.
 //
 // Same results as the straightforward form in vxrt_device.hpp (and therefore as Raytrace/DDARayTraversal,
-// VoxelRT/VolumeRaytracer.cu:176-525), but organised for 64-wide wavefronts:
+// VoxelRT/VolumeRaytracer.cu:176-525), but organised for 64-wide wavefronts.  Profiling the straightforward
+// kernel showed it is instruction-issue bound with the CU's single scalar unit as the hot spot (about one
+// s_and_saveexec/s_cbranch/s_or per vector instruction from nested divergent loops), so:
 //
-//  * ONE loop.  Every iteration performs one cell probe + one DDA advance for every lane that is walking,
-//    whether it is on the coarse grid or inside a brick, so lanes on different levels share the same VALU
-//    instructions instead of serialising nested loops behind exec-mask branches.
-//  * The rare, expensive events -- tight-box slab test on an occupied coarse cell (ST_BOX) and the
-//    end-of-walk transitions: brick entry, brick exit + re-seed with the ulp nudge, ray end (ST_END) --
-//    PARK the lane.  A __ballot vote runs a parked phase only when enough lanes wait for it (or nobody can
-//    walk), so its cost is amortised over many lanes; __ballot == 0 is the wave's early-out.
-//  * Per-ray invariants of the reference's per-walk / per-box arithmetic are hoisted: 1/(d or eps) of the slab
-//    test (VolumeRaytracer.cu:127-129) and |1/d| of the DDA (:199-201) are the same IEEE quotients for every
-//    walk of a ray, so they are divided once per ray.
-//  * Occupancy bits are fetched as 64-bit z-slices of an 8x8x8 tile (one aligned global_load_dwordx2) and kept
-//    in registers: x/y moves inside a tile re-use the slice without touching memory.  The next cell's slice is
-//    requested right after the advance, one iteration ahead of its test.
+//  * ONE loop.  Every iteration performs one cell probe + one DDA advance for every walking lane, whether it is
+//    on the coarse grid or inside a brick; lanes on different levels share the same vector instructions.
+//  * The hot path is straight-line and predicated: lane conditions live in VGPRs as 0/1 integers and are
+//    combined with vector AND/OR, state changes are arithmetic on a small state code, values are committed
+//    with v_cndmask.  No exec-mask branches; the occupancy word of the (clamped) current cell is loaded
+//    unconditionally, one global_load_dword per lane per iteration.
+//  * The rare, expensive events -- tight-box slab test on an occupied coarse cell (ST_BOX) and the end-of-walk
+//    transitions: brick entry, brick exit + re-seed with the ulp nudge, ray end (ST_END) -- PARK the lane.
+//    A __ballot vote runs a parked phase only when enough lanes wait for it (or nobody can walk), so its
+//    cost is amortised over many lanes; an all-zero __ballot is the wave's early-out.
+//  * Per-ray invariants are hoisted: 1/(d or eps) of the slab test (VolumeRaytracer.cu:127-129) and |1/d| of
+//    the DDA (:199-201) are the same IEEE quotients for every walk of a ray, so they are divided once per ray.
+//  * The reference advances the DDA once more on the exit iteration only to produce NextCell, which is read
+//    only after a coarse hit (:473); here that extra advance is reduced to picking its axis in the box phase.
 //  * The 8-byte cell_meta record read for the slab test also carries the brick's pool slot, so brick entry
 //    needs no second dependent load (the reference chases a 24-byte descriptor, then the brick pointer).
 #pragma once
@@ -25,6 +28,7 @@
 namespace vxrt {
 
 enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u };
+enum : uint32_t { WF_HIT = 1u, WF_OOB = 2u };
 
 // unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
 __device__ __forceinline__ f3 normal_decode(uint32_t c)
@@ -44,6 +48,8 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
     // ---- per-ray constants ---------------------------------------------------------------------
     const f3 d = active ? unit3(ray) : mk3(1.0f, 0.0f, 0.0f);
     const int sgx = d.x > 0 ? 1 : -1, sgy = d.y > 0 ? 1 : -1, sgz = d.z > 0 ? 1 : -1;
+    const int upx = d.x > 0 ? 1 : 0, upy = d.y > 0 ? 1 : 0, upz = d.z > 0 ? 1 : 0;
+    const uint32_t code_x = 1u | (d.x > 0 ? 0u : 4u), code_y = 2u | (d.y > 0 ? 0u : 4u), code_z = 3u | (d.z > 0 ? 0u : 4u);
     const float ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // slab-test reciprocals, :127-129
     const float ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
     const float ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
@@ -61,12 +67,10 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
         float nz = lo(az, bz), fz = hi(az, bz);
         float t_in = hi(hi(nx, ny), nz);
         float t_out = lo(lo(fx, fy), fz);
-        if (t_out < hi(t_in, 0.0f))
-            return false;
         p = mk3(s.x + t_in * d.x, s.y + t_in * d.y, s.z + t_in * d.z);
         code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
                             : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
-        return true;
+        return !(t_out < hi(t_in, 0.0f));
     };
 
     // ---- Raytrace-level state (:359-384) -------------------------------------------------------
@@ -90,54 +94,50 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
     int vx = 0, vy = 0, vz = 0;
 
     // ---- walk state (DDARayTraversal locals, :178-232) ------------------------------------------
-    bool fine = false;                 // level of the current walk
+    uint32_t fine = 0u;                // level of the current walk (0 coarse, 1 brick)
     f3 ws = start;                     // Params.start of the current walk
-    int cell_x, cell_y, cell_z;
-    float tn_x, tn_y, tn_z;
-    f3 point;
+    int cell_x = 0, cell_y = 0, cell_z = 0;
+    int lim_x = 0, lim_y = 0, lim_z = 0;  // dimension + edge padding (:216-232,:240)
+    float tn_x = 0, tn_y = 0, tn_z = 0;
+    f3 point = start;
     int it = 0, steps = 0;
-    bool w_hit = false, w_oob = false;
-    uint32_t w_code = 0;               // HitNormal of the current walk
-    int pad_x = 0, pad_y = 0, pad_z = 0;
-    int hx = 0, hy = 0, hz = 0;        // HitCell of a brick hit
+    uint32_t wf = 0u;                  // WF_HIT | WF_OOB of the current walk
+    uint32_t w_code = 0u;              // HitNormal of the current walk
+    uint32_t skip = 0u;                // 1: this cell was already probed (tight box missed), advance only
     // coarse results that outlive the coarse walk (:399-429,:438-488)
     int chx = 0, chy = 0, chz = 0;     // coarse HitCell
-    uint32_t c_code = 0;               // coarse HitNormal (the tight box's)
+    uint32_t c_code = 0u;              // coarse HitNormal (the tight box's)
     int nc_axis = 0;                   // NextCell = coarse HitCell + sgn on this axis
-    uint32_t slot = kEmptySlot;
-    // occupancy slice cache
+    uint32_t slot = 0u;
     const uint32_t* bits = W.coarse_bits;
-    uint32_t slice_key = 0xFFFFFFFFu;
-    uint2 slice = make_uint2(0u, 0u);
 
-    auto begin_walk = [&](f3 s, bool to_fine) {
+    auto begin_walk = [&](f3 s, uint32_t to_fine) {
         fine = to_fine;
         ws = s;
         cell_x = (int)s.x;
         cell_y = (int)s.y;
         cell_z = (int)s.z;
-        tn_x = d.x != 0 ? ((float)(cell_x + (sgx > 0)) - s.x) / d.x : kInf;
-        tn_y = d.y != 0 ? ((float)(cell_y + (sgy > 0)) - s.y) / d.y : kInf;
-        tn_z = d.z != 0 ? ((float)(cell_z + (sgz > 0)) - s.z) / d.z : kInf;
+        tn_x = d.x != 0 ? ((float)(cell_x + upx) - s.x) / d.x : kInf;
+        tn_y = d.y != 0 ? ((float)(cell_y + upy) - s.y) / d.y : kInf;
+        tn_z = d.z != 0 ? ((float)(cell_z + upz) - s.z) / d.z : kInf;
         point = s;
         it = 0;
         steps = 0;
-        w_hit = false;
-        w_oob = false;
-        w_code = 0;
+        wf = 0u;
+        w_code = 0u;
+        skip = 0u;
         // an occupied coarse cell always owns a brick (checked at upload, guaranteed by the device builder),
         // so a brick walk's dimensions are always f
         const int dmx = to_fine ? W.f : W.cx, dmy = to_fine ? W.f : W.cy, dmz = to_fine ? W.f : W.cz;
         const bool edge = cell_x == dmx || cell_y == dmy || cell_z == dmz;  // :216-232
-        pad_x = edge && d.x < 0;
-        pad_y = edge && d.y < 0;
-        pad_z = edge && d.z < 0;
-        slice_key = 0xFFFFFFFFu;
+        lim_x = dmx + ((edge && d.x < 0) ? 1 : 0);
+        lim_y = dmy + ((edge && d.y < 0) ? 1 : 0);
+        lim_z = dmz + ((edge && d.z < 0) ? 1 : 0);
     };
 
     uint32_t st = active ? ST_WALK : ST_DONE;
     if (active)
-        begin_walk(start, false);
+        begin_walk(start, 0u);
 
     for (;;) {
         const unsigned long long m_walk = __ballot(st == ST_WALK);
@@ -155,7 +155,7 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
                     f3 local = mk3(point.x * W.ff, point.y * W.ff, point.z * W.ff);
                     hit_pos = local;
                     const uint32_t ci = tiled_index(chx, chy, chz, W.ctw, W.ctwh);
-                    if (!(w_hit && !w_oob) || ci == last_ci) {
+                    if (wf != WF_HIT || ci == last_ci) {
                         st = ST_DONE;  // coarse miss / left the grid (:508-511), or the previous_cell guard (:402-407)
                     } else {
                         last_ci = ci;
@@ -164,22 +164,22 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
                         if (STATS)
                             cnt.brick_entries += 1;
                         bits = W.pool + (size_t)slot * W.brick_words;
-                        begin_walk(local, true);
+                        begin_walk(local, 1u);
                         st = ST_WALK;
                     }
                 } else {
                     const float fx = (float)chx, fy = (float)chy, fz = (float)chz;
                     hit_pos = mk3(point.x + fx * W.ff, point.y + fy * W.ff, point.z + fz * W.ff);
-                    if (w_hit) {  // :493-506
+                    if (wf & WF_HIT) {  // :493-506
                         out_code = (steps == 0) ? c_code : w_code;
-                        vx = chx * W.f + hx;
-                        vy = chy * W.f + hy;
-                        vz = chz * W.f + hz;
+                        vx = chx * W.f + min(cell_x, W.f - 1);  // brick HitCell = the clamped cell that was probed
+                        vy = chy * W.f + min(cell_y, W.f - 1);
+                        vz = chz * W.f + min(cell_z, W.f - 1);
                         ray_hit = true;
                         st = ST_DONE;
                     } else {  // brick missed: restart the coarse walk just past it (:431-491)
                         start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
-                        if (w_oob) {
+                        if (wf & WF_OOB) {
                             bool same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
                             if (same) {
                                 start.x = ulp_step(start.x, d.x < 0);
@@ -202,7 +202,7 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
                         }
                         if (total < max_steps) {  // the while condition, checked only here (:386)
                             bits = W.coarse_bits;
-                            begin_walk(start, false);
+                            begin_walk(start, 0u);
                             st = ST_WALK;
                         } else {
                             st = ST_DONE;
@@ -212,12 +212,9 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
             }
         }
 
-        bool advance = false, leaving = false;
-        const uint32_t st0 = st;  // lanes leaving the box test below must not probe again this iteration
-
         // ---- parked phase: tight-box test of an occupied coarse cell (:248-273) -------------------
-        if (vote_run(n_box, n_walk) && st0 == ST_BOX) {
-            {
+        if (vote_run(n_box, n_walk)) {
+            if (st == ST_BOX) {
                 const int qx = min(cell_x, W.cx - 1), qy = min(cell_y, W.cy - 1), qz = min(cell_z, W.cz - 1);
                 const uint32_t idx = tiled_index(qx, qy, qz, W.ctw, W.ctwh);
                 const uint2 meta = W.cell_meta[idx];
@@ -229,9 +226,9 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
                               ((float)((e >> 25) & 31u) + 1) * W.inv_f + (float)qz);
                 f3 bp;
                 uint32_t bc;
-                if (bmin.x <= bmax.x && slab(ws, bmin, bmax, bp, bc)) {
-                    w_hit = true;
-                    w_code = bc;
+                const bool box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
+                if (box_hit) {
+                    wf = WF_HIT;
                     if (it != 0)
                         point = bp;
                     chx = qx;
@@ -239,87 +236,66 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
                     chz = qz;
                     c_code = bc;
                     slot = meta.x;
-                    leaving = true;
-                }
-                advance = true;
-                st = ST_WALK;
-            }
-        } else if (st0 == ST_WALK) {
-            // ---- probe the current cell ----------------------------------------------------------
-            const int dmx = fine ? W.f : W.cx, dmy = fine ? W.f : W.cy, dmz = fine ? W.f : W.cz;
-            const bool inside = (unsigned)cell_x < (unsigned)(dmx + pad_x) && (unsigned)cell_y < (unsigned)(dmy + pad_y) &&
-                                (unsigned)cell_z < (unsigned)(dmz + pad_z);
-            advance = true;
-            if (!inside) {
-                w_oob = true;
-                leaving = true;
-            } else {
-                const int qx = min(cell_x, dmx - 1), qy = min(cell_y, dmy - 1), qz = min(cell_z, dmz - 1);
-                if (STATS) {
-                    if (fine)
-                        cnt.fine_probes += 1;
-                    else
-                        cnt.coarse_probes += 1;
-                }
-                const uint32_t idx = tiled_index(qx, qy, qz, fine ? W.ftw : W.ctw, fine ? W.ftwh : W.ctwh);
-                const uint32_t key = idx >> 6;
-                if (key != slice_key) {
-                    slice = reinterpret_cast<const uint2*>(bits)[key];
-                    slice_key = key;
-                }
-                const unsigned long long s64 = ((unsigned long long)slice.y << 32) | slice.x;
-                const bool solid = ((s64 >> (idx & 63u)) & 1ull) != 0ull;
-                if (solid) {
-                    if (fine) {
-                        w_hit = true;
-                        hx = qx;
-                        hy = qy;
-                        hz = qz;
-                        leaving = true;
-                    } else {
-                        st = ST_BOX;  // park for the tight-box test; the cell is not advanced yet
-                        advance = false;
-                    }
+                    // the exit iteration's extra advance (:290-322) only matters through NextCell's axis
+                    nc_axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
+                    st = ST_END;
+                } else {
+                    skip = 1u;  // not a hit: walk on without probing this cell again
+                    st = ST_WALK;
                 }
             }
         }
 
-        // ---- advance one cell (also on the exit iteration, :290-349) --------------------------------
-        if (advance) {
-            const bool ax0 = tn_x < tn_y && tn_x < tn_z;
-            const bool ax1 = !ax0 && (tn_y <= tn_x && tn_y < tn_z);
+        // ---- hot path: probe the current cell and advance, predicated on w = walking -----------------
+        {
+            const uint32_t w = (st == ST_WALK) ? 1u : 0u;
+            const bool is_fine = fine != 0u;
+            const int dm1x = is_fine ? W.f - 1 : W.cx - 1, dm1y = is_fine ? W.f - 1 : W.cy - 1,
+                      dm1z = is_fine ? W.f - 1 : W.cz - 1;
+            // 0 <= cell < dim + pad on all three axes, as one sign test: every (cell - lim) negative, no cell negative
+            const int in_bits = (cell_x - lim_x) & (cell_y - lim_y) & (cell_z - lim_z) & ~(cell_x | cell_y | cell_z);
+            const uint32_t in = (uint32_t)in_bits >> 31;
+            const int qx = min(max(cell_x, 0), dm1x), qy = min(max(cell_y, 0), dm1y), qz = min(max(cell_z, 0), dm1z);
+            const uint32_t idx = tiled_index(qx, qy, qz, is_fine ? W.ftw : W.ctw, is_fine ? W.ftwh : W.ctwh);
+            const uint32_t word = bits[idx >> 5];  // unconditional: the clamped cell is always a valid address
+            const uint32_t solid = (word >> (idx & 31u)) & 1u & ~skip;
+            if (STATS) {
+                const uint32_t probed = w & in & ~skip;
+                cnt.fine_probes += probed & fine;
+                cnt.coarse_probes += probed & ~fine;
+            }
+            const uint32_t leave_oob = w & (in ^ 1u);            // left the grid / brick: isOutOfBounds (:283-287)
+            const uint32_t leave_hit = w & in & solid & fine;     // solid voxel inside a brick (:276-280)
+            const uint32_t park = w & in & solid & (fine ^ 1u);   // occupied coarse cell: tight-box test pending
+            const uint32_t adv = w & in & (solid ^ 1u);
+            skip = skip & (w ^ 1u);
+
+            // DDA advance (:293-322), computed for every lane, committed where adv
+            const bool lt_xy = tn_x < tn_y, lt_xz = tn_x < tn_z, lt_yz = tn_y < tn_z;
+            const bool ax0 = lt_xy && lt_xz;
+            const bool ax1 = !lt_xy && lt_yz;  // tn_y <= tn_x && tn_y < tn_z; implies !ax0
             const float t = ax0 ? tn_x : (ax1 ? tn_y : tn_z);
-            const float crx = ax0 ? (float)(cell_x + (sgx > 0)) : ws.x + (t * d.x);
-            const float cry = ax1 ? (float)(cell_y + (sgy > 0)) : ws.y + (t * d.y);
-            const float crz = (!ax0 && !ax1) ? (float)(cell_z + (sgz > 0)) : ws.z + (t * d.z);
-            if (ax0) {
-                cell_x += sgx;
-                tn_x += tdx;
-            } else if (ax1) {
-                cell_y += sgy;
-                tn_y += tdy;
-            } else {
-                cell_z += sgz;
-                tn_z += tdz;
-            }
-            if (leaving) {
-                if (!fine)
-                    nc_axis = ax0 ? 0 : (ax1 ? 1 : 2);  // coarse NextCell; must survive the brick walk that follows
-                st = ST_END;
-            } else {
-                w_code = ax0 ? (1u | (sgx < 0 ? 4u : 0u)) : (ax1 ? (2u | (sgy < 0 ? 4u : 0u)) : (3u | (sgz < 0 ? 4u : 0u)));
-                const float fmax = W.ff;
-                if (fine && (crx < 0.0f || crx > fmax || cry < 0.0f || cry > fmax || crz < 0.0f || crz > fmax)) {
-                    w_oob = true;  // region check on the crossing point (:325-341): step not counted
-                    st = ST_END;
-                } else {
-                    steps += 1;
-                    point = mk3(crx, cry, crz);
-                    it += 1;
-                    if (it >= kMaxSteps)
-                        st = ST_END;  // walk exhausted without a verdict (:234)
-                }
-            }
+            const float crx = ax0 ? (float)(cell_x + upx) : ws.x + (t * d.x);
+            const float cry = ax1 ? (float)(cell_y + upy) : ws.y + (t * d.y);
+            const float crz = (ax0 || ax1) ? ws.z + (t * d.z) : (float)(cell_z + upz);
+            // region check on the crossing point, brick walks only (:325-341): [0,f]^3, step not counted
+            const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
+            const uint32_t region_oob = ((cmin < 0.0f || cmax > W.ff) ? 1u : 0u) & fine & adv;
+            const uint32_t ok = adv & (region_oob ^ 1u);
+            const bool commit = adv != 0u, counted = ok != 0u;
+            cell_x += (commit && ax0) ? sgx : 0;
+            cell_y += (commit && ax1) ? sgy : 0;
+            cell_z += (commit && !ax0 && !ax1) ? sgz : 0;
+            tn_x = (commit && ax0) ? tn_x + tdx : tn_x;
+            tn_y = (commit && ax1) ? tn_y + tdy : tn_y;
+            tn_z = (commit && !ax0 && !ax1) ? tn_z + tdz : tn_z;
+            w_code = counted ? (ax0 ? code_x : (ax1 ? code_y : code_z)) : w_code;
+            point = counted ? mk3(crx, cry, crz) : point;
+            steps += (int)ok;
+            it += (int)ok;
+            const uint32_t exhausted = ok & (it >= kMaxSteps ? 1u : 0u);  // walk ran out of iterations (:234)
+            wf |= leave_hit * WF_HIT | (leave_oob | region_oob) * WF_OOB;
+            st += park * ST_BOX + (leave_oob | leave_hit | region_oob | exhausted) * ST_END;  // st was ST_WALK (0) where w
         }
     }
 
