@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="c3_8k_1080p_shadow_bounce", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
-    ap.add_argument("--cpu-frames", type=int, default=2, help="frames of the workload timed on the host cores")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the workload timed on the host cores")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
     return ap.parse_args()
 
@@ -200,6 +200,18 @@ def main():
         print(json.dumps(result), flush=True)
 
 
+def host_cores() -> int:
+    """Cores this process may actually use: the scheduler affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts):
     """The CPU oracle (kind "port": this repo's C restatement of the reference algorithm) timed on the GPU box's
     host cores on a bounded sample of the same workload: `--cpu-frames` full frames.  The same frames double as a
@@ -207,7 +219,7 @@ def cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts):
     import torch
     from oracle import vxo
 
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     w = ctx.download_world()
     world = vxo.World.wrap(w["factor"], w["cdims"], w["coarse_bits"], w["brick_slot"], w["bounds"], w["pool"])
     rays = 0

@@ -1,0 +1,107 @@
+// voxelapp_headless.cpp -- the call sequence of the reference's VoxelApp/main.cu against the GPUDDA facade,
+// without SDL2: build the world, build the brickmap, upload, set the environment, then per frame
+// GetDirections + RenderScreen + device->host copy of the framebuffer (main.cu:18-69,165-167).  The fly camera
+// is a scripted path instead of keyboard/mouse input; the last frame is written as raw BGRA and as a PPM.
+//
+//   voxelapp_headless [world_edge=256] [frames=2] [out_prefix=frame] [width=320] [height=180] [shaded=0]
+#include "../include/GPUDDA/Renderer.h"
+#include "../include/GPUDDA/VoxelWorldBuilder.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+using namespace GPUDDA;
+using namespace GPUDDA::Graphics;
+
+int main(int argc, char** argv)
+{
+    const unsigned edge = argc > 1 ? (unsigned)atoi(argv[1]) : 256u;
+    const int frames = argc > 2 ? atoi(argv[2]) : 2;
+    const std::string prefix = argc > 3 ? argv[3] : "frame";
+    const uint32_t width = argc > 4 ? (uint32_t)atoi(argv[4]) : 320u, height = argc > 5 ? (uint32_t)atoi(argv[5]) : 180u;
+    const bool shaded = argc > 6 && atoi(argv[6]) != 0;
+
+    int factor = 32;
+    auto t0 = std::chrono::high_resolution_clock::now();
+    auto buffer = CreateVoxels(make_uint3(edge, edge, edge));
+    auto t1 = std::chrono::high_resolution_clock::now();
+    std::cout << "Voxel generation time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
+
+    auto buffers = GenerateLowresVoxelBuffer(buffer, factor);
+    auto t2 = std::chrono::high_resolution_clock::now();
+    std::cout << "Buffer generation time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms" << std::endl;
+    delete[] buffer.grid.Raw();
+
+    VoxelRaytracer3D* raytracer = new VoxelRaytracer3D(1);
+    auto low_res_buffer = std::get<0>(buffers);
+    auto low_res_grid_data = std::get<1>(buffers);
+    auto bounds = std::get<2>(buffers);
+    auto count = (size_t)low_res_buffer.dimensions[0] * low_res_buffer.dimensions[1] * low_res_buffer.dimensions[2];
+    raytracer->UploadVoxelBuffer(low_res_buffer);
+    raytracer->UploadVoxelBufferDatas(low_res_grid_data, count);
+    raytracer->UploadVoxelBufferDataBounds(bounds, count);
+    raytracer->SetFactor(factor);
+
+    float3 cam_pos = make_float3(edge * 0.25f, edge * 0.9f, edge * 0.25f);
+    float3 cam_up, cam_right, cam_forward;
+    float3 cam_eular = make_float3(-0.45f, 0.7f, 0.0f);
+
+    Environment env;
+    const float inv = 1.0f / std::sqrt(3.0f);
+    env.LightDirection = make_float3(1.0f * inv, 1.0f * inv, 1.0f * inv);
+    env.LightColor = make_float3(2, 2, 2);
+    env.AmbientColor = make_float3(0.5f, 0.5f, 0.5f);
+    SetEnvironment(env);
+    SetFOV(90);
+    SetOrthoWindowSize(make_float2(10, 10));
+    if (shaded) {  // the README screenshots' configuration; default = the checked-in debug view
+        RenderSwitches s;
+        s.DebugView = false;
+        s.ShadowRay = true;
+        s.BounceSamples = 1;
+        SetRenderSwitches(s);
+    }
+
+    void* d_pixels = nullptr;
+    if (hipMalloc(&d_pixels, (size_t)width * height * sizeof(BGRA8888)) != hipSuccess)
+        return 1;
+    (void)hipMemset(d_pixels, 255, (size_t)width * height * sizeof(BGRA8888));
+    std::vector<BGRA8888> pixels((size_t)width * height);
+
+    double avgFrameTime = 0.0;
+    for (int i = 0; i < frames; ++i) {
+        auto f0 = std::chrono::high_resolution_clock::now();
+        GetDirections(cam_eular, &cam_forward, &cam_up, &cam_right);
+        RenderScreen(raytracer, width, height, d_pixels, cam_pos, cam_forward, cam_up, cam_right);
+        (void)hipMemcpy(pixels.data(), d_pixels, pixels.size() * sizeof(BGRA8888), hipMemcpyDeviceToHost);
+        auto f1 = std::chrono::high_resolution_clock::now();
+        double td = std::chrono::duration_cast<std::chrono::microseconds>(f1 - f0).count() / 1000.0;
+        avgFrameTime = i == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
+    }
+    std::cout << "Avg FPS: " << 1000.0 / avgFrameTime << std::endl;
+
+    std::ofstream raw(prefix + ".bgra", std::ios::binary);
+    raw.write(reinterpret_cast<const char*>(pixels.data()), (std::streamsize)(pixels.size() * sizeof(BGRA8888)));
+    std::ofstream ppm(prefix + ".ppm", std::ios::binary);
+    ppm << "P6\n" << width << " " << height << "\n255\n";
+    for (const auto& p : pixels) {
+        const char rgb[3] = {(char)p.r, (char)p.g, (char)p.b};
+        ppm.write(rgb, 3);
+    }
+    // a few batch queries through VoxelRaytracer3D::Raytrace
+    std::vector<float3> o(4, cam_pos), d = {make_float3(0, -1, 0), make_float3(1, -1, 0), make_float3(0, 1, 0), cam_forward};
+    auto res = raytracer->Raytrace(o, d);
+    for (int i = 0; i < 4; ++i)
+        std::printf("ray %d valid=%d steps=%d voxel=%d\n", i, (int)res.valid[i], res.steps[i], res.voxelIndex[i]);
+    (void)hipFree(d_pixels);
+    delete raytracer;
+    return 0;
+}

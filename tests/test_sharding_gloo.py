@@ -1,0 +1,81 @@
+"""N > 1 path on CPU: the strip plan and the gather collective (gloo, world_size 2 and 3).  Each rank packs
+the rows it owns out of a known frame exactly as the render kernel packs them (compact mode), the packed shards
+are gathered to rank 0 with voxelengine_amd.sharding.gather_frame, and a torch reference of the de-interleave
+(the product uses the HIP kernel behind vxrt_deinterleave_strips; that one is covered by the GPU tests) must
+rebuild the frame byte for byte."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from voxelengine_amd import sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _reference_deinterleave(plan):
+    def fn(shards, frame):
+        sh = shards.view(plan.world_size, plan.max_rows, plan.width, 4)
+        for r in range(plan.world_size):
+            for lr in range(plan.rows_of(r)):
+                frame[plan.frame_row(r, lr)] = sh[r, lr]
+    return fn
+
+
+def _worker(rank, world, port, W, H, rows, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = sharding.ShardPlan(W, H, rows, world, rank)
+    g = torch.Generator().manual_seed(1234)
+    full = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, generator=g)   # same on every rank
+    local = torch.zeros(plan.shard_bytes, dtype=torch.uint8)
+    lv = local.view(plan.max_rows, W, 4)
+    for lr in range(plan.local_rows):
+        lv[lr] = full[plan.frame_row(rank, lr)]
+    shards = torch.zeros((world, plan.shard_bytes), dtype=torch.uint8) if rank == 0 else None
+    frame = torch.zeros((H, W, 4), dtype=torch.uint8) if rank == 0 else None
+    out = sharding.gather_frame(plan, local, shards, frame, _reference_deinterleave(plan))
+    if rank == 0:
+        torch.save(dict(ok=bool(torch.equal(out, full))), out_path)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,W,H,rows", [(2, 64, 40, 16), (2, 48, 33, 8), (3, 32, 50, 16)])
+def test_gather_rebuilds_frame_gloo(tmp_path, world, W, H, rows):
+    out_path = str(tmp_path / "res.pt")
+    mp.spawn(_worker, args=(world, _free_port(), W, H, rows, out_path), nprocs=world, join=True)
+    assert torch.load(out_path)["ok"]
+
+
+def test_plan_matches_the_c_abi_row_count():
+    import voxelengine_amd as vx
+    for H, rows, world in [(1080, 16, 8), (1080, 16, 2), (2160, 16, 8), (33, 8, 2), (50, 16, 3), (7, 16, 4)]:
+        covered = np.zeros(H, int)
+        for r in range(world):
+            plan = sharding.ShardPlan(64, H, rows, world, r)
+            assert plan.local_rows == vx.compact_rows(H, rows, world, r)
+            for lr in range(plan.local_rows):
+                covered[plan.frame_row(r, lr)] += 1
+        assert (covered == 1).all()          # every frame row belongs to exactly one shard
+
+
+def test_single_rank_is_a_plain_deinterleave():
+    plan = sharding.ShardPlan(16, 20, 8, 1, 0)
+    full = torch.arange(20 * 16 * 4, dtype=torch.int64).remainder(251).to(torch.uint8).view(20, 16, 4)
+    frame = torch.zeros_like(full)
+    sharding.gather_frame(plan, full.reshape(-1).clone(), None, frame, _reference_deinterleave(plan))
+    assert torch.equal(frame, full)
