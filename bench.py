@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="c3_8k_1080p_shadow_bounce", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the workload timed on the host cores")
+    ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
     return ap.parse_args()
 
