@@ -116,6 +116,8 @@ typedef struct vxrt_frame_stats {
     uint64_t coarse_probes; /* Nc: in-range coarse cell probes */
     uint64_t brick_entries; /* Nb */
     uint64_t fine_probes;   /* Nf: in-range brick cell probes */
+    uint64_t dbg[4];        /* wave-loop diagnostics (collect_stats launches): iterations, walking lanes summed
+                               over iterations, end-phase runs, box-phase runs */
 } vxrt_frame_stats;
 
 typedef struct vxrt_render_flags {

@@ -66,22 +66,27 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
-def test_straightforward_kernel_variant_agrees(eng, vxo):
-    """Kernel variant 1 (per-lane loops, kept for A/B timing) gives the same bits as the default wave-level
-    state machine and as the oracle."""
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
+    """Variants: 0 wave state machine (one lane per pixel), 1 straightforward per-lane loops, 2 persistent waves
+    with a pixel queue.  All give the oracle's bits, in every render mode."""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
     o, d = helpers.mixed_rays(w.dims, 20000, 21)
     cpu = w.trace_batch(o, d)
+    default = ctx.kernel_variant
     try:
-        ctx.set_kernel_variant(1)
+        ctx.set_kernel_variant(variant)
         _assert_batch_equal(ctx.Raytrace(o, d), cpu)
-        res = _render_both(eng, vxo, w, 160, 96, "A", frame_number=5, shadow=1, bounce_samples=2)
-        _assert_frame_equal(*res)
+        _assert_frame_equal(*_render_both(eng, vxo, w, 160, 96, "A", frame_number=5, shadow=1, bounce_samples=2))
+        _assert_frame_equal(*_render_both(eng, vxo, w, 150, 90, "B", frame_number=4, shadow=1, bounce_samples=1,
+                                          bounce_all_hits=1))
+        _assert_frame_equal(*_render_both(eng, vxo, w, 160, 90, "D", frame_number=2, mode=1, checkerboard=1))
+        _assert_frame_equal(*_render_both(eng, vxo, w, 128, 96, "A", ortho=1, ortho_size=(60.0, 60.0), shadow=1))
+        _assert_frame_equal(*_render_both(eng, vxo, w, 131, 77, "C"))
     finally:
-        ctx.set_kernel_variant(0)
-    _assert_batch_equal(ctx.Raytrace(o, d), cpu)
+        ctx.set_kernel_variant(default)
 
 
 def test_known_answer_rays_on_gpu(eng, vxo):

@@ -17,7 +17,7 @@ for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "k_render" not in k: continue
-        name = "wave" if "k_render_wave" in k else "direct"
+        name = "wave" if "k_render_wave" in k else ("persist" if "persist" in k else "direct")
         per[(name, row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
     for (name, did, cn), v in per.items():
         acc[cn][name].append(v)

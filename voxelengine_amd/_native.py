@@ -37,7 +37,7 @@ class WorldInfo(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("bounce_rays", C.c_uint64),
                 ("primary_hits", C.c_uint64), ("coarse_probes", C.c_uint64), ("brick_entries", C.c_uint64),
-                ("fine_probes", C.c_uint64)]
+                ("fine_probes", C.c_uint64), ("dbg", C.c_uint64 * 4)]
 
     def total_rays(self) -> int:
         return int(self.primary_rays + self.shadow_rays + self.bounce_rays)
@@ -80,7 +80,7 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except ImportError:
         pass
-    path = _build.LIB_PATH
+    path = os.environ.get("VXRT_LIB", _build.LIB_PATH)  # VXRT_LIB: A/B builds of the same library (tools/)
     if not os.path.exists(path) or os.environ.get("VXRT_REBUILD"):
         _build.build_lib()
     if not os.path.exists(path):

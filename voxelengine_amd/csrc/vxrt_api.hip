@@ -50,7 +50,8 @@ struct vxrt_ctx {
     float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
     float ortho[2] = {10.0f, 10.0f};
     uint32_t frame_counter = 0;
-    int kernel_variant = 0;          // 0 = wave state machine, 1 = straightforward loops
+    int kernel_variant = 0;          // 0 = wave state machine, 1 = straightforward loops, 2 = persistent waves
+    unsigned persistent_waves = 4096;
     unsigned long long* d_stats = nullptr;
 };
 
@@ -76,6 +77,8 @@ int check_shape(int factor, const int cd[3])
     for (int a = 0; a < 3; ++a)
         if (cd[a] <= 0 || cd[a] % 8 != 0 || cd[a] > 65535)
             return fail(VXRT_ERR_INVALID, "coarse dimensions must be positive multiples of 8 (tiled-linear layout)");
+    if ((uint64_t)(cd[0] / 8) * (uint64_t)(cd[1] / 8) >= (1ull << 24) || (uint64_t)cd[0] * cd[1] * cd[2] >= (1ull << 32))
+        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit tiled indices");
     return VXRT_OK;
 }
 
@@ -154,9 +157,15 @@ int vxrt_create(int device, vxrt_ctx** out)
     if (!c)
         return fail(VXRT_ERR_NOMEM, "out of host memory");
     c->device = device;
-    hipError_t e = hipMalloc((void**)&c->d_stats, vxrt::kStatCount * sizeof(unsigned long long));
+    // counters + one extra slot used as the persistent kernel's tile counter
+    hipError_t e = hipMalloc((void**)&c->d_stats, (vxrt::kStatCount + 1) * sizeof(unsigned long long));
     if (e == hipSuccess)
-        e = hipMemset(c->d_stats, 0, vxrt::kStatCount * sizeof(unsigned long long));
+        e = hipMemset(c->d_stats, 0, (vxrt::kStatCount + 1) * sizeof(unsigned long long));
+    if (e == hipSuccess) {
+        hipDeviceProp_t prop;
+        e = hipGetDeviceProperties(&prop, device);
+        c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
+    }
     if (e != hipSuccess) {
         delete c;
         return fail(VXRT_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
@@ -179,8 +188,8 @@ int vxrt_destroy(vxrt_ctx* c)
 
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant > 1)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave) or 1 (direct)");
+    if (!c || variant < 0 || variant > 2)
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct) or 2 (persistent)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }
@@ -435,6 +444,8 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
     A.color_aov = fl->d_color_aov;
     A.hit_aov = (long long*)fl->d_hit_aov;
     A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
+    A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount);
+    A.persistent_waves = c->persistent_waves;
     vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
     VX_HIP(hipGetLastError());
     return VXRT_OK;
@@ -456,6 +467,10 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     out->coarse_probes = h[vxrt::kStatCoarseProbes];
     out->brick_entries = h[vxrt::kStatBrickEntries];
     out->fine_probes = h[vxrt::kStatFineProbes];
+    out->dbg[0] = h[vxrt::kStatDbgIters];
+    out->dbg[1] = h[vxrt::kStatDbgWalkLanes];
+    out->dbg[2] = h[vxrt::kStatDbgEndRuns];
+    out->dbg[3] = h[vxrt::kStatDbgBoxRuns];
     return VXRT_OK;
 }
 

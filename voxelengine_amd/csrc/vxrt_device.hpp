@@ -56,12 +56,16 @@ struct WorldView {
 
 struct RayCounters {
     uint32_t coarse_probes, brick_entries, fine_probes;
+    // loop diagnostics of the wave tracer (probe-counting kernel variant only; wave-uniform values)
+    uint32_t iters = 0, walk_lanes = 0, end_runs = 0, box_runs = 0;
 };
 
 // 8x8x8 tiled-linear bit address (GetSampleIndex, VolumeRaytracer.cuh:107-131)
 __device__ __forceinline__ uint32_t tiled_index(int x, int y, int z, int tw, int twh)
 {
-    uint32_t tile = (uint32_t)((x >> 3) + (y >> 3) * tw + (z >> 3) * twh);
+    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): tiles per axis < 2^13, tiles per slice < 2^24
+    // (checked when a world is uploaded or built)
+    uint32_t tile = (uint32_t)(x >> 3) + __umul24((uint32_t)(y >> 3), (uint32_t)tw) + __umul24((uint32_t)(z >> 3), (uint32_t)twh);
     return tile * 512u + (uint32_t)((x & 7) | ((y & 7) << 3) | ((z & 7) << 6));
 }
 

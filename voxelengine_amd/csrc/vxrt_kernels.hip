@@ -451,6 +451,10 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
             atomicAdd(&A.stats[kStatCoarseProbes], p0);
             atomicAdd(&A.stats[kStatBrickEntries], p1);
             atomicAdd(&A.stats[kStatFineProbes], p2);
+            atomicAdd(&A.stats[kStatDbgIters], (unsigned long long)cnt.iters);
+            atomicAdd(&A.stats[kStatDbgWalkLanes], (unsigned long long)cnt.walk_lanes);
+            atomicAdd(&A.stats[kStatDbgEndRuns], (unsigned long long)cnt.end_runs);
+            atomicAdd(&A.stats[kStatDbgBoxRuns], (unsigned long long)cnt.box_runs);
         }
     }
 }
@@ -496,7 +500,14 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
     }
 }
 
-// variant 0 = wave state machine (product default), 1 = straightforward per-lane loops (A/B and cross-check)
+}  // namespace vxrt
+
+#include "vxrt_persist.hpp"
+
+namespace vxrt {
+
+// variant 0 = wave state machine, one lane per pixel; 1 = straightforward per-lane loops (A/B and cross-check);
+// 2 = persistent waves pulling pixels from a tile queue
 void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
 {
     // one wave per workgroup: no wave waits for a slower sibling before its slot is reused (+5 % measured)
@@ -507,6 +518,16 @@ void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t str
     if (grid.x == 0 || grid.y == 0)
         return;
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
+    if (variant == 2) {
+        const unsigned ntiles = ((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u);
+        const unsigned waves = ntiles < A.persistent_waves ? ntiles : A.persistent_waves;
+        (void)hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
+        if (stats)
+            hipLaunchKernelGGL(k_render_persist<true>, dim3(waves), dim3(64), lds, stream, A);
+        else
+            hipLaunchKernelGGL(k_render_persist<false>, dim3(waves), dim3(64), lds, stream, A);
+        return;
+    }
     if (variant == 1) {
         if (stats)
             hipLaunchKernelGGL(k_render<true>, grid, block, lds, stream, A);

@@ -14,6 +14,10 @@ enum StatSlot {
     kStatCoarseProbes,
     kStatBrickEntries,
     kStatFineProbes,
+    kStatDbgIters,      // wave-loop iterations, summed over waves (diagnostics)
+    kStatDbgWalkLanes,  // walking lanes summed over those iterations
+    kStatDbgEndRuns,
+    kStatDbgBoxRuns,
     kStatCount
 };
 
@@ -34,6 +38,8 @@ struct RenderArgs {
     float* color_aov;
     long long* hit_aov;
     unsigned long long* stats;
+    unsigned int* tile_counter;  // persistent kernel: next 8x8 tile of the launch grid to hand out (zeroed per launch)
+    unsigned int persistent_waves;
 };
 
 struct BatchArgs {

@@ -1,0 +1,310 @@
+// vxrt_persist.hpp -- screenDispatch (VoxelRT/Renderer.cu:179-276) as a persistent wave-level kernel.
+//
+// The per-pixel ray chain of the reference -- primary ray, shadow ray for a hit (Renderer.cu:97-102), occlusion /
+// bounce samples (:121-165), shading, tonemap, store -- is a dependent sequence per pixel but independent across
+// pixels.  Launching "one lane = one pixel, three trace loops one after the other" leaves most lanes idle: measured
+// useful-lane share of the traversal loop was ~46 % (rays of one 8x8 tile differ in length, sky pixels have no
+// secondary rays, bounce rays go everywhere).  Here a wavefront is persistent:
+//
+//   * the launch grid's 8x8 pixel tiles are a queue (one global atomic per 64 pixels);
+//   * each lane carries ONE pixel through its whole chain inside the single traversal loop of vxrt_wave.hpp; the
+//     moment its chain ends it stores the pixel and takes the next pixel from the wave's current tile
+//     (ranks from the ballot mask, no LDS, no per-lane atomics), so all 64 lanes stay in the walk phase;
+//   * "ray finished" is one more parked state (ST_DONE), voted like the box/end phases: the per-pixel work (camera
+//     ray, shading, next ray set-up with its divisions and square root) runs for many lanes at once.
+//
+// Results are identical to the one-lane-one-pixel kernels: every pixel is a pure function of its inputs.
+#pragma once
+
+#include "vxrt_kernels.hpp"
+#include "vxrt_wave.hpp"
+
+namespace vxrt {
+
+enum : uint32_t { PX_NONE = 0u, PX_PRIMARY = 1u, PX_SHADOW = 2u, PX_BOUNCE = 3u };
+
+struct PixelCoords {
+    uint32_t tx, ty;  // launch coordinates of the reference's thread (crosshair, RNG seed)
+    int x, y;         // frame pixel
+    int out_row;      // row in the destination buffers
+    bool live;
+};
+
+// launch (tx,row) -> pixel, shared by all render kernels (Renderer.cu:183-196 + this build's strip sharding)
+__device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_t tx, uint32_t row)
+{
+    PixelCoords c;
+    c.tx = tx;
+    c.ty = row;
+    const bool sharded = A.strip_count > 1;
+    if (sharded && !A.checkerboard) {
+        uint32_t strip = (row / (uint32_t)A.strip_rows) * (uint32_t)A.strip_count + (uint32_t)A.strip_index;
+        c.ty = strip * (uint32_t)A.strip_rows + row % (uint32_t)A.strip_rows;
+    }
+    c.live = row < A.launch_rows;
+    c.x = (int)tx;
+    c.y = (int)c.ty;
+    if (A.checkerboard) {
+        c.y *= 2;
+        if ((c.x % 2) == 0)
+            c.y += 1;
+        if (A.frame_number % 2 == 0)
+            c.y += 1;
+    }
+    c.live = c.live && (uint32_t)c.x < A.width && (uint32_t)c.y < A.height;
+    if (c.live && sharded && ((uint32_t)c.y / (uint32_t)A.strip_rows) % (uint32_t)A.strip_count != (uint32_t)A.strip_index)
+        c.live = false;
+    c.out_row = c.y;
+    if (A.compact && sharded)
+        c.out_row = (int)((((uint32_t)c.y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
+                          (uint32_t)c.y % (uint32_t)A.strip_rows);
+    return c;
+}
+
+// getRayDirection / getRayDirectionOrtho (Renderer.cu:44-70)
+__device__ __forceinline__ void camera_ray(const RenderArgs& A, int x, int y, f3& origin, f3& ray)
+{
+    const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
+    origin = A.origin;
+    if (A.ortho) {
+        ray = A.fwd;
+        origin = origin + ((A.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+        origin = origin + (A.up * (v * 2 - 1)) * A.ortho_y;
+    } else {
+        float su = u * 2 - 1, sv = v * 2 - 1;
+        ray.x = A.fwd.x + su * A.kx * A.right.x + sv * A.ky * A.up.x;
+        ray.y = A.fwd.y + su * A.kx * A.right.y + sv * A.ky * A.up.y;
+        ray.z = A.fwd.z + su * A.kx * A.right.z + sv * A.ky * A.up.z;
+        ray = unit3(ray);
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
+{
+    const WorldView& W = A.W;
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lane_below = (1ull << lane) - 1ull;
+
+    WaveTracer<STATS> T;
+    T.init(W);  // st = ST_DONE: every lane starts by asking for a pixel
+    uint32_t stage = PX_NONE;
+    uint32_t px_tx = 0, px_row = 0;
+    f3 position = mk3(0, 0, 0), color = mk3(0, 0, 0);
+    uint32_t pcode = 0;       // primary hit normal (step direction) code
+    int p_steps = 0;
+    float occl = 0.0f;
+    int sample = 0;
+    uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
+
+    // the wave's share of the tile queue (wave-uniform)
+    const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
+    uint32_t tile = 0, tile_used = 64u;
+    bool drained = false;
+
+    const f3 L = A.light_dir;
+    const f3 sray = unit3(L);
+
+    auto store_pixel = [&](const PixelCoords& pc, bool hit, f3 normal, f3 pos, f3 shaded) {
+        PixelSink sink{A, pc.out_row};
+        const int Wd = (int)A.width, Hd = (int)A.height;
+        f3 origin, ray;
+        camera_ray(A, pc.x, pc.y, origin, ray);
+        if (hit) {
+            if (A.mode == 1) {  // DEBUG_VIEW quadrants, Renderer.cu:215-243
+                f3 dv = pos - origin;
+                float dist = sqrtf(dot3(dv, dv));
+                const float wrap = (float)(1.0 + 1e-6);
+                f3 hp = mk3(fmodf(pos.x / 128.0f, wrap), fmodf(pos.y / 128.0f, wrap), fmodf(pos.z / 128.0f, wrap));
+                if (pc.x < (Wd >> 1) && pc.y < (Hd >> 1))
+                    sink.put(pc.x, pc.y, normal);
+                else if (pc.x >= (Wd >> 1) && pc.y < (Hd >> 1))
+                    sink.put(pc.x, pc.y, hp);
+                else if (pc.x < (Wd >> 1)) {
+                } else
+                    sink.put(pc.x, pc.y, mk3(dist * 0.01f, 0, 0));
+            } else {
+                f3 c = mk3(shaded.x / (shaded.x + 1.0f), shaded.y / (shaded.y + 1.0f), shaded.z / (shaded.z + 1.0f));  // Tonemap
+                c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
+                sink.put(pc.x, pc.y, c);
+            }
+        } else {
+            sink.put(pc.x, pc.y, ray);  // Renderer.cu:254-258
+        }
+        if (pc.tx == (A.width >> 1) && pc.ty == (A.height >> 1))  // crosshair on launch coordinates, :261-268
+            sink.put(pc.x, pc.y, mk3(10, 10, 10));
+        if (A.mode == 1 && pc.x < (Wd >> 1) && pc.y > (Hd >> 1))  // :270-275
+            sink.put(pc.x, pc.y, mk3((float)p_steps / 256.0f, 0, 0));
+    };
+
+    auto begin_bounce = [&](const PixelCoords& pc, f3 normal, int i) {  // one sample of Renderer.cu:128-142
+        const uint32_t seed = pc.ty * A.width + pc.tx;
+        const uint32_t si = seed + (uint32_t)i * 1000u + (A.frame_number + 1u) * 1000u;
+        f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
+        sd = unit3(sd);
+        if (dot3(sd, normal) < 0)
+            sd = reflect3(sd, normal);
+        n_bounce += 1;
+        T.begin_ray(W, position + normal * 0.01f, sd, 8);
+        stage = PX_BOUNCE;
+    };
+
+    for (;;) {
+        const unsigned long long m_walk = __ballot(T.st == ST_WALK);
+        const unsigned long long m_box = __ballot(T.st == ST_BOX);
+        const unsigned long long m_end = __ballot(T.st == ST_END);
+        const unsigned long long m_next = __ballot(T.st == ST_DONE);
+        if ((m_walk | m_box | m_end | m_next) == 0ull)
+            break;
+        const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end), n_next = __popcll(m_next);
+
+        // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
+        if (vote_run(n_next, n_walk + n_box + n_end)) {
+            if (T.st == ST_DONE && stage != PX_NONE) {
+                const PixelCoords pc = pixel_coords(A, px_tx, px_row);
+                TraceResult r;
+                T.result(W, r);
+                bool finalize = false, do_shade = false, shadowed = false;
+                f3 normal;
+                if (stage == PX_PRIMARY) {
+                    pcode = (r.hit && r.steps == 0) ? T.entry_code : T.out_code;
+                    p_steps = r.steps;
+                    position = r.pos;
+                    if (A.hit_aov)
+                        A.hit_aov[(size_t)pc.out_row * A.width + (size_t)pc.x] =
+                            r.hit ? (long long)r.vx + (long long)W.X * ((long long)r.vy + (long long)W.Y * (long long)r.vz) : -1ll;
+                    n_hits += r.hit ? 1u : 0u;
+                    color = mk3(0, 0, 0);
+                    if (!(r.hit && A.mode == 0)) {
+                        stage = r.hit ? PX_PRIMARY : PX_NONE;  // remember hit/miss for the store below
+                        finalize = true;
+                    } else if (A.shadow) {
+                        n_shadow += 1;
+                        T.begin_ray(W, position + sray * 0.01f, sray, kMaxSteps);  // Renderer.cu:97-102
+                        stage = PX_SHADOW;
+                    } else {
+                        do_shade = true;
+                    }
+                } else if (stage == PX_SHADOW) {
+                    shadowed = r.hit;
+                    do_shade = true;
+                }
+                {
+                    const f3 pn = normal_decode(pcode);
+                    normal = mk3(-pn.x, -pn.y, -pn.z);  // Renderer.cu:212
+                }
+                if (do_shade) {  // calculateColor, Renderer.cu:104-118
+                    f3 origin, ray;
+                    camera_ray(A, pc.x, pc.y, origin, ray);
+                    const float l_dot = hi(dot3(normal, L), 0) * (float)(shadowed ? 0 : 1);
+                    f3 diffuse = A.light_color * l_dot;
+                    float up_dot = normal.x * 0.0f + normal.y * 1.0f + normal.z * 0.0f;
+                    float t = (float)((double)up_dot * 0.5 + 0.5);
+                    color = diffuse + A.ambient * (0.25f + t * (1.0f - 0.25f));
+                    if (!shadowed) {
+                        f3 view = unit3(position - origin);
+                        f3 refl = reflect3(L, normal);
+                        float spec = pow32(hi(dot3(view, refl), 0));
+                        color.x += spec * A.light_color.x;
+                        color.y += spec * A.light_color.y;
+                        color.z += spec * A.light_color.z;
+                    }
+                    if (l_dot == 0 || A.bounce_all_hits) {  // Renderer.cu:121
+                        occl = 0.0f;
+                        sample = 0;
+                        if (A.bounce_samples > 0) {
+                            begin_bounce(pc, normal, 0);
+                        } else {
+                            color = color * 1.0f;  // samples == 0: occlusion = 1 (Renderer.cu:159-164)
+                            stage = PX_PRIMARY;
+                            finalize = true;
+                        }
+                    } else {
+                        stage = PX_PRIMARY;
+                        finalize = true;
+                    }
+                } else if (stage == PX_BOUNCE && T.st == ST_DONE) {
+                    if (!r.hit)
+                        occl += 1.0f;
+                    sample += 1;
+                    if (sample < A.bounce_samples) {
+                        begin_bounce(pc, normal, sample);
+                    } else {
+                        occl /= (float)A.bounce_samples;
+                        color = color * occl;
+                        stage = PX_PRIMARY;
+                        finalize = true;
+                    }
+                }
+                if (finalize) {
+                    store_pixel(pc, stage != PX_NONE, normal, position, color);
+                    stage = PX_NONE;
+                }
+            }
+            // hand out pixels of the wave's tile(s) to the lanes that are free
+            unsigned long long want = __ballot(T.st == ST_DONE && stage == PX_NONE);
+            while (want != 0ull && !drained) {
+                if (tile_used >= 64u) {
+                    uint32_t t = 0;
+                    if (lane == 0)
+                        t = atomicAdd(A.tile_counter, 1u);
+                    tile = (uint32_t)__shfl((int)t, 0, 64);
+                    if (tile >= ntiles) {
+                        drained = true;
+                        break;
+                    }
+                    tile_used = 0u;
+                }
+                const uint32_t avail = 64u - tile_used;
+                const bool wants = ((want >> lane) & 1ull) != 0ull;
+                const uint32_t rank = (uint32_t)__popcll(want & lane_below);
+                if (wants && rank < avail) {
+                    const uint32_t p = tile_used + rank;
+                    px_tx = (tile % ntx) * 8u + (p & 7u);
+                    px_row = (tile / ntx) * 8u + (p >> 3);
+                    const PixelCoords pc = pixel_coords(A, px_tx, px_row);
+                    if (pc.live) {
+                        f3 origin, ray;
+                        camera_ray(A, pc.x, pc.y, origin, ray);
+                        n_primary += 1;
+                        T.begin_ray(W, origin, ray, kMaxSteps);
+                        stage = PX_PRIMARY;
+                    }
+                }
+                const uint32_t asked = (uint32_t)__popcll(want);
+                tile_used += asked < avail ? asked : avail;
+                want = __ballot(T.st == ST_DONE && stage == PX_NONE);
+            }
+            if (drained && T.st == ST_DONE && stage == PX_NONE)
+                T.st = ST_IDLE;
+        }
+
+        if (vote_run(n_end, n_walk + n_box)) {
+            if (T.st == ST_END)
+                T.phase_end(W);
+        }
+        if (vote_run(n_box, n_walk)) {
+            if (T.st == ST_BOX)
+                T.phase_box(W);
+        }
+        T.step(W);
+    }
+
+    unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_bounce), s3 = wave_sum(n_hits);
+    if (lane == 0 && A.stats) {
+        atomicAdd(&A.stats[kStatPrimary], s0);
+        atomicAdd(&A.stats[kStatShadow], s1);
+        atomicAdd(&A.stats[kStatBounce], s2);
+        atomicAdd(&A.stats[kStatPrimaryHits], s3);
+    }
+    if (STATS) {
+        unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries), p2 = wave_sum(T.cnt.fine_probes);
+        if (lane == 0 && A.stats) {
+            atomicAdd(&A.stats[kStatCoarseProbes], p0);
+            atomicAdd(&A.stats[kStatBrickEntries], p1);
+            atomicAdd(&A.stats[kStatFineProbes], p2);
+        }
+    }
+}
+
+}  // namespace vxrt

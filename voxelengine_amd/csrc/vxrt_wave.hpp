@@ -7,9 +7,9 @@
 //
 //  * ONE loop.  Every iteration performs one cell probe + one DDA advance for every walking lane, whether it is
 //    on the coarse grid or inside a brick; lanes on different levels share the same vector instructions.
-//  * The hot path is straight-line and predicated: lane conditions live in VGPRs as 0/1 integers and are
-//    combined with vector AND/OR, state changes are arithmetic on a small state code, values are committed
-//    with v_cndmask.  No exec-mask branches; the occupancy word of the (clamped) current cell is loaded
+//  * The hot path (WaveTracer::step) is straight-line and predicated: lane conditions live in VGPRs as 0/1
+//    integers and are combined with vector AND/OR, state changes are arithmetic on a small state code, values are
+//    committed with v_cndmask.  No exec-mask branches; the occupancy word of the (clamped) current cell is loaded
 //    unconditionally, one global_load_dword per lane per iteration.
 //  * The rare, expensive events -- tight-box slab test on an occupied coarse cell (ST_BOX) and the end-of-walk
 //    transitions: brick entry, brick exit + re-seed with the ulp nudge, ray end (ST_END) -- PARK the lane.
@@ -27,7 +27,7 @@
 
 namespace vxrt {
 
-enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u };
+enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u, ST_IDLE = 4u };
 enum : uint32_t { WF_HIT = 1u, WF_OOB = 2u };
 
 // unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
@@ -38,27 +38,65 @@ __device__ __forceinline__ f3 normal_decode(uint32_t c)
     return mk3(a == 1u ? v : 0.0f, a == 2u ? v : 0.0f, a == 3u ? v : 0.0f);
 }
 
-// run a parked phase when its lanes are at least a quarter of the walking lanes (or nobody walks)
-__device__ __forceinline__ bool vote_run(int parked, int walking) { return parked > 0 && parked * 4 >= walking; }
+// run a parked phase when its lanes are at least a quarter of the other live lanes (or nobody else can move)
+#ifndef VXRT_VOTE_NUM
+#define VXRT_VOTE_NUM 4
+#endif
+__device__ __forceinline__ bool vote_run(int parked, int others) { return parked > 0 && parked * VXRT_VOTE_NUM >= others; }
 
+// One lane's ray: Raytrace-level state (:359-384), the current DDARayTraversal walk (:178-232) and the coarse
+// results that outlive the coarse walk (:399-429,:438-488).  All members live in registers.
 template <bool STATS>
-__device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
-                           TraceResult& out, RayCounters& cnt)
-{
-    // ---- per-ray constants ---------------------------------------------------------------------
-    const f3 d = active ? unit3(ray) : mk3(1.0f, 0.0f, 0.0f);
-    const int sgx = d.x > 0 ? 1 : -1, sgy = d.y > 0 ? 1 : -1, sgz = d.z > 0 ? 1 : -1;
-    const int upx = d.x > 0 ? 1 : 0, upy = d.y > 0 ? 1 : 0, upz = d.z > 0 ? 1 : 0;
-    const uint32_t code_x = 1u | (d.x > 0 ? 0u : 4u), code_y = 2u | (d.y > 0 ? 0u : 4u), code_z = 3u | (d.z > 0 ? 0u : 4u);
-    const float ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // slab-test reciprocals, :127-129
-    const float ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
-    const float ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
-    const float tdx = d.x != 0 ? fabsf(ivx) : kInf;       // |1/d|, :199-201 (same quotient as ivx when d != 0)
-    const float tdy = d.y != 0 ? fabsf(ivy) : kInf;
-    const float tdz = d.z != 0 ? fabsf(ivz) : kInf;
+struct WaveTracer {
+    // per-ray constants
+    f3 d;                 // normalised direction
+    float ivx, ivy, ivz;  // 1/(d or eps), slab test
+    float tdx, tdy, tdz;  // |1/d| or inf, DDA
+    int max_steps;
+    // Raytrace level
+    f3 start;
+    uint32_t entry_code, last_ci, out_code;
+    int total;
+    f3 hit_pos;
+    bool ray_hit;
+    // current walk
+    uint32_t st, fine, wf, w_code, skip;
+    f3 ws, point;
+    int cell_x, cell_y, cell_z, lim_x, lim_y, lim_z;
+    float tn_x, tn_y, tn_z;
+    int steps;  // stepsTaken; also the reference's loop index: an iteration continues exactly when a step is counted
+    // coarse results kept across the brick walk
+    int chx, chy, chz, nc_axis;
+    uint32_t c_code, slot;
+    const uint32_t* bits;
+    RayCounters cnt;
+
+    __device__ __forceinline__ void init(const WorldView& W)
+    {
+        st = ST_DONE;
+        fine = wf = w_code = skip = 0u;
+        d = mk3(1.0f, 0.0f, 0.0f);
+        ivx = ivy = ivz = 1.0f;
+        tdx = tdy = tdz = 1.0f;
+        max_steps = 0;
+        start = ws = point = hit_pos = mk3(0, 0, 0);
+        entry_code = out_code = 0u;
+        last_ci = 0xFFFFFFFFu;
+        total = 0;
+        ray_hit = false;
+        cell_x = cell_y = cell_z = 0;
+        lim_x = lim_y = lim_z = 0;
+        tn_x = tn_y = tn_z = 0.0f;
+        steps = 0;
+        chx = chy = chz = nc_axis = 0;
+        c_code = slot = 0u;
+        bits = W.coarse_bits;
+        cnt = RayCounters{0, 0, 0};
+    }
 
     // slab test against [bmin,bmax] from point s with the hoisted reciprocals (RayIntersectsAABB, :124-174)
-    auto slab = [&](f3 s, f3 bmin, f3 bmax, f3& p, uint32_t& code) -> bool {
+    __device__ __forceinline__ bool slab(f3 s, f3 bmin, f3 bmax, f3& p, uint32_t& code) const
+    {
         float ax = (bmin.x - s.x) * ivx, bx = (bmax.x - s.x) * ivx;
         float ay = (bmin.y - s.y) * ivy, by = (bmax.y - s.y) * ivy;
         float az = (bmin.z - s.z) * ivz, bz = (bmax.z - s.z) * ivz;
@@ -71,57 +109,19 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
         code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
                             : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
         return !(t_out < hi(t_in, 0.0f));
-    };
-
-    // ---- Raytrace-level state (:359-384) -------------------------------------------------------
-    f3 start = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
-    uint32_t entry_code = 0;
-    if (active && !(start.x >= 0 && start.y >= 0 && start.z >= 0 && start.x < (float)W.cx && start.y < (float)W.cy &&
-                    start.z < (float)W.cz)) {
-        const float e = (float)1e-6;
-        f3 p;
-        uint32_t c;
-        if (slab(start, mk3(e, e, e), mk3(W.wmax_x, W.wmax_y, W.wmax_z), p, c)) {
-            start = p;
-            entry_code = c;
-        }
     }
-    uint32_t last_ci = 0xFFFFFFFFu;  // previous_cell as its tiled index (unique per cell); none yet
-    int total = 0;
-    f3 hit_pos = mk3(0, 0, 0);
-    bool ray_hit = false;
-    uint32_t out_code = 0;
-    int vx = 0, vy = 0, vz = 0;
 
-    // ---- walk state (DDARayTraversal locals, :178-232) ------------------------------------------
-    uint32_t fine = 0u;                // level of the current walk (0 coarse, 1 brick)
-    f3 ws = start;                     // Params.start of the current walk
-    int cell_x = 0, cell_y = 0, cell_z = 0;
-    int lim_x = 0, lim_y = 0, lim_z = 0;  // dimension + edge padding (:216-232,:240)
-    float tn_x = 0, tn_y = 0, tn_z = 0;
-    f3 point = start;
-    int it = 0, steps = 0;
-    uint32_t wf = 0u;                  // WF_HIT | WF_OOB of the current walk
-    uint32_t w_code = 0u;              // HitNormal of the current walk
-    uint32_t skip = 0u;                // 1: this cell was already probed (tight box missed), advance only
-    // coarse results that outlive the coarse walk (:399-429,:438-488)
-    int chx = 0, chy = 0, chz = 0;     // coarse HitCell
-    uint32_t c_code = 0u;              // coarse HitNormal (the tight box's)
-    int nc_axis = 0;                   // NextCell = coarse HitCell + sgn on this axis
-    uint32_t slot = 0u;
-    const uint32_t* bits = W.coarse_bits;
-
-    auto begin_walk = [&](f3 s, uint32_t to_fine) {
+    __device__ __forceinline__ void begin_walk(const WorldView& W, f3 s, uint32_t to_fine)
+    {
         fine = to_fine;
         ws = s;
         cell_x = (int)s.x;
         cell_y = (int)s.y;
         cell_z = (int)s.z;
-        tn_x = d.x != 0 ? ((float)(cell_x + upx) - s.x) / d.x : kInf;
-        tn_y = d.y != 0 ? ((float)(cell_y + upy) - s.y) / d.y : kInf;
-        tn_z = d.z != 0 ? ((float)(cell_z + upz) - s.z) / d.z : kInf;
+        tn_x = d.x != 0 ? ((float)(cell_x + (d.x > 0 ? 1 : 0)) - s.x) / d.x : kInf;
+        tn_y = d.y != 0 ? ((float)(cell_y + (d.y > 0 ? 1 : 0)) - s.y) / d.y : kInf;
+        tn_z = d.z != 0 ? ((float)(cell_z + (d.z > 0 ? 1 : 0)) - s.z) / d.z : kInf;
         point = s;
-        it = 0;
         steps = 0;
         wf = 0u;
         w_code = 0u;
@@ -133,182 +133,255 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
         lim_x = dmx + ((edge && d.x < 0) ? 1 : 0);
         lim_y = dmy + ((edge && d.y < 0) ? 1 : 0);
         lim_z = dmz + ((edge && d.z < 0) ? 1 : 0);
-    };
+    }
 
-    uint32_t st = active ? ST_WALK : ST_DONE;
-    if (active)
-        begin_walk(start, 0u);
+    // Raytrace's prologue (:359-384): per-ray constants, world entry, first coarse walk
+    __device__ __forceinline__ void begin_ray(const WorldView& W, f3 origin, f3 ray, int max_steps_)
+    {
+        d = unit3(ray);
+        ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // :127-129
+        ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
+        ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
+        tdx = d.x != 0 ? fabsf(ivx) : kInf;        // :199-201 (same quotient as ivx when d != 0)
+        tdy = d.y != 0 ? fabsf(ivy) : kInf;
+        tdz = d.z != 0 ? fabsf(ivz) : kInf;
+        max_steps = max_steps_;
+        start = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
+        entry_code = 0u;
+        if (!(start.x >= 0 && start.y >= 0 && start.z >= 0 && start.x < (float)W.cx && start.y < (float)W.cy &&
+              start.z < (float)W.cz)) {
+            const float e = (float)1e-6;
+            f3 p;
+            uint32_t c;
+            if (slab(start, mk3(e, e, e), mk3(W.wmax_x, W.wmax_y, W.wmax_z), p, c)) {
+                start = p;
+                entry_code = c;
+            }
+        }
+        last_ci = 0xFFFFFFFFu;  // previous_cell as its tiled index (unique per cell); none yet
+        total = 0;
+        hit_pos = mk3(0, 0, 0);
+        ray_hit = false;
+        out_code = 0u;
+        bits = W.coarse_bits;
+        begin_walk(W, start, 0u);
+        st = ST_WALK;
+    }
 
-    for (;;) {
-        const unsigned long long m_walk = __ballot(st == ST_WALK);
-        const unsigned long long m_box = __ballot(st == ST_BOX);
-        const unsigned long long m_end = __ballot(st == ST_END);
-        if ((m_walk | m_box | m_end) == 0ull)
-            break;  // every lane of the wave is done
-        const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
-
-        // ---- parked phase: end of a walk (:395-511) ---------------------------------------------
-        if (vote_run(n_end, n_walk + n_box)) {
-            if (st == ST_END) {
-                total += steps;
-                if (!fine) {
-                    f3 local = mk3(point.x * W.ff, point.y * W.ff, point.z * W.ff);
-                    hit_pos = local;
-                    const uint32_t ci = tiled_index(chx, chy, chz, W.ctw, W.ctwh);
-                    if (wf != WF_HIT || ci == last_ci) {
-                        st = ST_DONE;  // coarse miss / left the grid (:508-511), or the previous_cell guard (:402-407)
-                    } else {
-                        last_ci = ci;
-                        const float fx = (float)chx, fy = (float)chy, fz = (float)chz;
-                        local = mk3(local.x - fx * W.ff, local.y - fy * W.ff, local.z - fz * W.ff);
-                        if (STATS)
-                            cnt.brick_entries += 1;
-                        bits = W.pool + (size_t)slot * W.brick_words;
-                        begin_walk(local, 1u);
-                        st = ST_WALK;
-                    }
-                } else {
-                    const float fx = (float)chx, fy = (float)chy, fz = (float)chz;
-                    hit_pos = mk3(point.x + fx * W.ff, point.y + fy * W.ff, point.z + fz * W.ff);
-                    if (wf & WF_HIT) {  // :493-506
-                        out_code = (steps == 0) ? c_code : w_code;
-                        vx = chx * W.f + min(cell_x, W.f - 1);  // brick HitCell = the clamped cell that was probed
-                        vy = chy * W.f + min(cell_y, W.f - 1);
-                        vz = chz * W.f + min(cell_z, W.f - 1);
-                        ray_hit = true;
-                        st = ST_DONE;
-                    } else {  // brick missed: restart the coarse walk just past it (:431-491)
-                        start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
-                        if (wf & WF_OOB) {
-                            bool same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
-                            if (same) {
-                                start.x = ulp_step(start.x, d.x < 0);
-                                start.y = ulp_step(start.y, d.y < 0);
-                                start.z = ulp_step(start.z, d.z < 0);
-                                same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
-                                if (same) {
-                                    const int ncx = chx + (nc_axis == 0 ? sgx : 0), ncy = chy + (nc_axis == 1 ? sgy : 0),
-                                              ncz = chz + (nc_axis == 2 ? sgz : 0);
-                                    float gx = (float)ncx - start.x, gy = (float)ncy - start.y, gz = (float)ncz - start.z;
-                                    float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
-                                    if (mx < my && mx < mz)
-                                        start.x += gx;
-                                    else if (my < mx && my < mz)
-                                        start.y += gy;
-                                    else
-                                        start.z += gz;
-                                }
-                            }
-                        }
-                        if (total < max_steps) {  // the while condition, checked only here (:386)
-                            bits = W.coarse_bits;
-                            begin_walk(start, 0u);
-                            st = ST_WALK;
-                        } else {
-                            st = ST_DONE;
+    // parked phase: end of a walk (:395-511); call for lanes with st == ST_END
+    __device__ __forceinline__ void phase_end(const WorldView& W)
+    {
+        const int sgx = d.x > 0 ? 1 : -1, sgy = d.y > 0 ? 1 : -1, sgz = d.z > 0 ? 1 : -1;
+        total += steps;
+        const float fx = (float)chx, fy = (float)chy, fz = (float)chz;
+        // both continuations (enter the brick / restart the coarse walk) share ONE begin_walk below: its three
+        // IEEE divisions are the bulk of this phase
+        bool go = false;
+        uint32_t to_fine = 0u;
+        f3 ns = start;
+        if (!fine) {
+            hit_pos = mk3(point.x * W.ff, point.y * W.ff, point.z * W.ff);
+            const uint32_t ci = tiled_index(chx, chy, chz, W.ctw, W.ctwh);
+            if (wf != WF_HIT || ci == last_ci) {
+                st = ST_DONE;  // coarse miss / left the grid (:508-511), or the previous_cell guard (:402-407)
+            } else {
+                last_ci = ci;
+                ns = mk3(hit_pos.x - fx * W.ff, hit_pos.y - fy * W.ff, hit_pos.z - fz * W.ff);
+                if (STATS)
+                    cnt.brick_entries += 1;
+                bits = W.pool + (size_t)slot * W.brick_words;
+                to_fine = 1u;
+                go = true;
+            }
+        } else {
+            hit_pos = mk3(point.x + fx * W.ff, point.y + fy * W.ff, point.z + fz * W.ff);
+            if (wf & WF_HIT) {  // :493-506
+                out_code = (steps == 0) ? c_code : w_code;
+                ray_hit = true;
+                st = ST_DONE;
+            } else {  // brick missed: restart the coarse walk just past it (:431-491)
+                start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
+                if (wf & WF_OOB) {
+                    bool same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
+                    if (same) {
+                        start.x = ulp_step(start.x, d.x < 0);
+                        start.y = ulp_step(start.y, d.y < 0);
+                        start.z = ulp_step(start.z, d.z < 0);
+                        same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
+                        if (same) {
+                            const int ncx = chx + (nc_axis == 0 ? sgx : 0), ncy = chy + (nc_axis == 1 ? sgy : 0),
+                                      ncz = chz + (nc_axis == 2 ? sgz : 0);
+                            float gx = (float)ncx - start.x, gy = (float)ncy - start.y, gz = (float)ncz - start.z;
+                            float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
+                            if (mx < my && mx < mz)
+                                start.x += gx;
+                            else if (my < mx && my < mz)
+                                start.y += gy;
+                            else
+                                start.z += gz;
                         }
                     }
                 }
-            }
-        }
-
-        // ---- parked phase: tight-box test of an occupied coarse cell (:248-273) -------------------
-        if (vote_run(n_box, n_walk)) {
-            if (st == ST_BOX) {
-                const int qx = min(cell_x, W.cx - 1), qy = min(cell_y, W.cy - 1), qz = min(cell_z, W.cz - 1);
-                const uint32_t idx = tiled_index(qx, qy, qz, W.ctw, W.ctwh);
-                const uint2 meta = W.cell_meta[idx];
-                const uint32_t e = meta.y;
-                f3 bmin = mk3(((float)(e & 31u) + 0) * W.inv_f + (float)qx, ((float)((e >> 5) & 31u) + 0) * W.inv_f + (float)qy,
-                              ((float)((e >> 10) & 31u) + 0) * W.inv_f + (float)qz);
-                f3 bmax = mk3(((float)((e >> 15) & 31u) + 1) * W.inv_f + (float)qx,
-                              ((float)((e >> 20) & 31u) + 1) * W.inv_f + (float)qy,
-                              ((float)((e >> 25) & 31u) + 1) * W.inv_f + (float)qz);
-                f3 bp;
-                uint32_t bc;
-                const bool box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
-                if (box_hit) {
-                    wf = WF_HIT;
-                    if (it != 0)
-                        point = bp;
-                    chx = qx;
-                    chy = qy;
-                    chz = qz;
-                    c_code = bc;
-                    slot = meta.x;
-                    // the exit iteration's extra advance (:290-322) only matters through NextCell's axis
-                    nc_axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
-                    st = ST_END;
+                if (total < max_steps) {  // the while condition, checked only here (:386)
+                    bits = W.coarse_bits;
+                    ns = start;
+                    go = true;
                 } else {
-                    skip = 1u;  // not a hit: walk on without probing this cell again
-                    st = ST_WALK;
+                    st = ST_DONE;
                 }
             }
         }
-
-        // ---- hot path: probe the current cell and advance, predicated on w = walking -----------------
-        {
-            const uint32_t w = (st == ST_WALK) ? 1u : 0u;
-            const bool is_fine = fine != 0u;
-            const int dm1x = is_fine ? W.f - 1 : W.cx - 1, dm1y = is_fine ? W.f - 1 : W.cy - 1,
-                      dm1z = is_fine ? W.f - 1 : W.cz - 1;
-            // 0 <= cell < dim + pad on all three axes, as one sign test: every (cell - lim) negative, no cell negative
-            const int in_bits = (cell_x - lim_x) & (cell_y - lim_y) & (cell_z - lim_z) & ~(cell_x | cell_y | cell_z);
-            const uint32_t in = (uint32_t)in_bits >> 31;
-            const int qx = min(max(cell_x, 0), dm1x), qy = min(max(cell_y, 0), dm1y), qz = min(max(cell_z, 0), dm1z);
-            const uint32_t idx = tiled_index(qx, qy, qz, is_fine ? W.ftw : W.ctw, is_fine ? W.ftwh : W.ctwh);
-            const uint32_t word = bits[idx >> 5];  // unconditional: the clamped cell is always a valid address
-            const uint32_t solid = (word >> (idx & 31u)) & 1u & ~skip;
-            if (STATS) {
-                const uint32_t probed = w & in & ~skip;
-                cnt.fine_probes += probed & fine;
-                cnt.coarse_probes += probed & ~fine;
-            }
-            const uint32_t leave_oob = w & (in ^ 1u);            // left the grid / brick: isOutOfBounds (:283-287)
-            const uint32_t leave_hit = w & in & solid & fine;     // solid voxel inside a brick (:276-280)
-            const uint32_t park = w & in & solid & (fine ^ 1u);   // occupied coarse cell: tight-box test pending
-            const uint32_t adv = w & in & (solid ^ 1u);
-            skip = skip & (w ^ 1u);
-
-            // DDA advance (:293-322), computed for every lane, committed where adv
-            const bool lt_xy = tn_x < tn_y, lt_xz = tn_x < tn_z, lt_yz = tn_y < tn_z;
-            const bool ax0 = lt_xy && lt_xz;
-            const bool ax1 = !lt_xy && lt_yz;  // tn_y <= tn_x && tn_y < tn_z; implies !ax0
-            const float t = ax0 ? tn_x : (ax1 ? tn_y : tn_z);
-            const float crx = ax0 ? (float)(cell_x + upx) : ws.x + (t * d.x);
-            const float cry = ax1 ? (float)(cell_y + upy) : ws.y + (t * d.y);
-            const float crz = (ax0 || ax1) ? ws.z + (t * d.z) : (float)(cell_z + upz);
-            // region check on the crossing point, brick walks only (:325-341): [0,f]^3, step not counted
-            const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
-            const uint32_t region_oob = ((cmin < 0.0f || cmax > W.ff) ? 1u : 0u) & fine & adv;
-            const uint32_t ok = adv & (region_oob ^ 1u);
-            const bool commit = adv != 0u, counted = ok != 0u;
-            cell_x += (commit && ax0) ? sgx : 0;
-            cell_y += (commit && ax1) ? sgy : 0;
-            cell_z += (commit && !ax0 && !ax1) ? sgz : 0;
-            tn_x = (commit && ax0) ? tn_x + tdx : tn_x;
-            tn_y = (commit && ax1) ? tn_y + tdy : tn_y;
-            tn_z = (commit && !ax0 && !ax1) ? tn_z + tdz : tn_z;
-            w_code = counted ? (ax0 ? code_x : (ax1 ? code_y : code_z)) : w_code;
-            point = counted ? mk3(crx, cry, crz) : point;
-            steps += (int)ok;
-            it += (int)ok;
-            const uint32_t exhausted = ok & (it >= kMaxSteps ? 1u : 0u);  // walk ran out of iterations (:234)
-            wf |= leave_hit * WF_HIT | (leave_oob | region_oob) * WF_OOB;
-            st += park * ST_BOX + (leave_oob | leave_hit | region_oob | exhausted) * ST_END;  // st was ST_WALK (0) where w
+        if (go) {
+            begin_walk(W, ns, to_fine);
+            st = ST_WALK;
         }
     }
 
-    out.hit = ray_hit;
-    out.steps = total;
-    out.normal = normal_decode(out_code);
-    out.pos = hit_pos;
-    out.vx = vx;
-    out.vy = vy;
-    out.vz = vz;
-    if (ray_hit && total == 0) {  // :518-522
-        out.pos = mk3(start.x * W.ff, start.y * W.ff, start.z * W.ff);
-        out.normal = normal_decode(entry_code);
+    // parked phase: tight-box test of an occupied coarse cell (:248-273); call for lanes with st == ST_BOX
+    __device__ __forceinline__ void phase_box(const WorldView& W)
+    {
+        const int qx = min(cell_x, W.cx - 1), qy = min(cell_y, W.cy - 1), qz = min(cell_z, W.cz - 1);
+        const uint32_t idx = tiled_index(qx, qy, qz, W.ctw, W.ctwh);
+        const uint2 meta = W.cell_meta[idx];
+        const uint32_t e = meta.y;
+        f3 bmin = mk3(((float)(e & 31u) + 0) * W.inv_f + (float)qx, ((float)((e >> 5) & 31u) + 0) * W.inv_f + (float)qy,
+                      ((float)((e >> 10) & 31u) + 0) * W.inv_f + (float)qz);
+        f3 bmax = mk3(((float)((e >> 15) & 31u) + 1) * W.inv_f + (float)qx, ((float)((e >> 20) & 31u) + 1) * W.inv_f + (float)qy,
+                      ((float)((e >> 25) & 31u) + 1) * W.inv_f + (float)qz);
+        f3 bp;
+        uint32_t bc;
+        const bool box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
+        if (box_hit) {
+            wf = WF_HIT;
+            if (steps != 0)  // `step != 0`, :266
+                point = bp;
+            chx = qx;
+            chy = qy;
+            chz = qz;
+            c_code = bc;
+            slot = meta.x;
+            // the exit iteration's extra advance (:290-322) only matters through NextCell's axis
+            nc_axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
+            st = ST_END;
+        } else {
+            skip = 1u;  // not a hit: walk on without probing this cell again
+            st = ST_WALK;
+        }
+    }
+
+    // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane
+    __device__ __forceinline__ void step(const WorldView& W)
+    {
+        const uint32_t w = (st == ST_WALK) ? 1u : 0u;
+        const bool is_fine = fine != 0u;
+        const int dm1x = is_fine ? W.f - 1 : W.cx - 1, dm1y = is_fine ? W.f - 1 : W.cy - 1,
+                  dm1z = is_fine ? W.f - 1 : W.cz - 1;
+        // 0 <= cell < dim + pad on all three axes, as one sign test: every (cell - lim) negative, no cell negative
+        const int in_bits = (cell_x - lim_x) & (cell_y - lim_y) & (cell_z - lim_z) & ~(cell_x | cell_y | cell_z);
+        const uint32_t in = (uint32_t)in_bits >> 31;
+        // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); an out-of-range
+        // lane reads word 0 instead, so the unconditional load below always has a valid address
+        const int qx = min(cell_x, dm1x), qy = min(cell_y, dm1y), qz = min(cell_z, dm1z);
+        const uint32_t idx_raw = tiled_index(qx, qy, qz, is_fine ? W.ftw : W.ctw, is_fine ? W.ftwh : W.ctwh);
+        const uint32_t idx = in ? idx_raw : 0u;
+        const uint32_t word = bits[idx >> 5];
+        const uint32_t solid = (word >> (idx & 31u)) & 1u & ~skip;
+        if (STATS) {
+            const uint32_t probed = w & in & ~skip;
+            cnt.fine_probes += probed & fine;
+            cnt.coarse_probes += probed & ~fine;
+        }
+        const uint32_t leave_oob = w & (in ^ 1u);            // left the grid / brick: isOutOfBounds (:283-287)
+        const uint32_t leave_hit = w & in & solid & fine;     // solid voxel inside a brick (:276-280)
+        const uint32_t park = w & in & solid & (fine ^ 1u);   // occupied coarse cell: tight-box test pending
+        const uint32_t adv = w & in & (solid ^ 1u);
+        skip = skip & (w ^ 1u);
+
+        // DDA advance (:293-322), computed for every lane, committed where adv
+        const bool upx = d.x > 0, upy = d.y > 0, upz = d.z > 0;
+        const bool lt_xy = tn_x < tn_y, lt_xz = tn_x < tn_z, lt_yz = tn_y < tn_z;
+        const bool ax0 = lt_xy && lt_xz;
+        const bool ax1 = !lt_xy && lt_yz;  // tn_y <= tn_x && tn_y < tn_z; implies !ax0
+        const float t = ax0 ? tn_x : (ax1 ? tn_y : tn_z);
+        const float crx = ax0 ? (float)(cell_x + (upx ? 1 : 0)) : ws.x + (t * d.x);
+        const float cry = ax1 ? (float)(cell_y + (upy ? 1 : 0)) : ws.y + (t * d.y);
+        const float crz = (ax0 || ax1) ? ws.z + (t * d.z) : (float)(cell_z + (upz ? 1 : 0));
+        // region check on the crossing point, brick walks only (:325-341): [0,f]^3, step not counted
+        const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
+        const uint32_t region_oob = ((cmin < 0.0f || cmax > W.ff) ? 1u : 0u) & fine & adv;
+        const uint32_t ok = adv & (region_oob ^ 1u);
+        const bool commit = adv != 0u, counted = ok != 0u;
+        cell_x += (commit && ax0) ? (upx ? 1 : -1) : 0;
+        cell_y += (commit && ax1) ? (upy ? 1 : -1) : 0;
+        cell_z += (commit && !ax0 && !ax1) ? (upz ? 1 : -1) : 0;
+        tn_x = (commit && ax0) ? tn_x + tdx : tn_x;
+        tn_y = (commit && ax1) ? tn_y + tdy : tn_y;
+        tn_z = (commit && !ax0 && !ax1) ? tn_z + tdz : tn_z;
+        const uint32_t code = ax0 ? (1u | (upx ? 0u : 4u)) : (ax1 ? (2u | (upy ? 0u : 4u)) : (3u | (upz ? 0u : 4u)));
+        w_code = counted ? code : w_code;
+        point = counted ? mk3(crx, cry, crz) : point;
+        steps += (int)ok;
+        const uint32_t exhausted = ok & (steps >= kMaxSteps ? 1u : 0u);  // walk ran out of iterations (:234)
+        wf |= leave_hit * WF_HIT | (leave_oob | region_oob) * WF_OOB;
+        st += park * ST_BOX + (leave_oob | leave_hit | region_oob | exhausted) * ST_END;  // st was ST_WALK (0) where w
+    }
+
+    // Raytrace's epilogue (:514-523)
+    __device__ __forceinline__ void result(const WorldView& W, TraceResult& out) const
+    {
+        out.hit = ray_hit;
+        out.steps = total;
+        out.normal = normal_decode(out_code);
+        out.pos = hit_pos;
+        // brick HitCell = the clamped cell that was probed last (the walk does not advance past a hit)
+        out.vx = chx * W.f + min(cell_x, W.f - 1);
+        out.vy = chy * W.f + min(cell_y, W.f - 1);
+        out.vz = chz * W.f + min(cell_z, W.f - 1);
+        if (ray_hit && total == 0) {
+            out.pos = mk3(start.x * W.ff, start.y * W.ff, start.z * W.ff);
+            out.normal = normal_decode(entry_code);
+        }
+    }
+};
+
+// one ray per lane, entered by the whole wave at a converged point
+template <bool STATS>
+__device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
+                           TraceResult& out, RayCounters& cnt)
+{
+    WaveTracer<STATS> T;
+    T.init(W);
+    if (active)
+        T.begin_ray(W, origin, ray, max_steps);
+    for (;;) {
+        const unsigned long long m_walk = __ballot(T.st == ST_WALK);
+        const unsigned long long m_box = __ballot(T.st == ST_BOX);
+        const unsigned long long m_end = __ballot(T.st == ST_END);
+        if ((m_walk | m_box | m_end) == 0ull)
+            break;  // every lane of the wave is done
+        const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
+        if (STATS) {
+            cnt.iters += 1;
+            cnt.end_runs += vote_run(n_end, n_walk + n_box) ? 1u : 0u;
+            cnt.box_runs += vote_run(n_box, n_walk) ? 1u : 0u;
+        }
+        if (vote_run(n_end, n_walk + n_box)) {
+            if (T.st == ST_END)
+                T.phase_end(W);
+        }
+        if (vote_run(n_box, n_walk)) {
+            if (T.st == ST_BOX)
+                T.phase_box(W);
+        }
+        if (STATS)
+            cnt.walk_lanes += (uint32_t)__popcll(__ballot(T.st == ST_WALK));
+        T.step(W);
+    }
+    T.result(W, out);
+    if (STATS) {
+        cnt.coarse_probes += T.cnt.coarse_probes;
+        cnt.brick_entries += T.cnt.brick_entries;
+        cnt.fine_probes += T.cnt.fine_probes;
     }
 }
 

@@ -59,6 +59,7 @@ class Context:
         N.check(self._L.vxrt_create(device, C.byref(h)))
         self._h = h
         self.device = device
+        self.kernel_variant = 0
 
     def close(self):
         if getattr(self, "_h", None):
@@ -182,8 +183,10 @@ class Context:
         return st if want_stats else None
 
     def set_kernel_variant(self, variant: int) -> None:
-        """0 = wave-level state machine (default), 1 = straightforward per-lane loops (A/B, cross-check)."""
+        """0 = wave-level state machine, 1 = straightforward per-lane loops (A/B, cross-check), 2 = persistent
+        waves with a pixel queue."""
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
+        self.kernel_variant = int(variant)
 
     def synchronize(self) -> None:
         N.check(self._L.vxrt_synchronize(self._h))
