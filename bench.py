@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development only: all ranks share cuda:0 and the gather goes through gloo/host memory, to "
+                         "exercise the N>1 code path on a one-GPU box (numbers are meaningless)")
     return ap.parse_args()
 
 
@@ -74,11 +77,18 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    rehearse = args.rehearse_on_one_gpu and world > 1
+    if rehearse:
+        local_rank = 0  # every rank on the one GPU; collectives through gloo and host memory
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if rehearse else dev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     X, Y, Z, F, gen, W, H, shadow, bounce = WORKLOADS[args.workload]
     ctx = vx.Context(local_rank)
@@ -108,18 +118,29 @@ def main():
     def deinterleave(sh, fr):
         ctx.deinterleave_strips(W, H, plan.strip_rows, world, sh, plan.shard_bytes, fr)
 
+    # N > 1: two-deep pipeline, the RCCL gather of frame k overlaps the render of frame k+1
+    pipe = None
+    if world > 1 and not rehearse:
+        pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frame, deinterleave)
+
     def step(i, ev=None):
         name, pos, f, u, r = cams[i % len(cams)]
-        target = frame if world == 1 else local
+        target = frame if world == 1 else (pipe.local(i) if pipe else local)
         if ev is not None:
             ev[0].record()
         ctx.RenderScreen(W, H, target, pos, f, u, r, opts(i + 1))
         if ev is not None:
             ev[1].record()
-        if world > 1:
-            sharding.gather_frame(plan, local, shards, frame, deinterleave)
+        if pipe:
+            pipe.submit(i)
+        elif world > 1:
+            host = torch.zeros((world, plan.shard_bytes), dtype=torch.uint8) if rank == 0 else None
+            sharding.gather_frame(plan, local.cpu(), host, frame,
+                                  lambda sh, fr: (shards.copy_(sh), deinterleave(shards, fr)))
 
     def fence():
+        if pipe:
+            pipe.flush()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -143,13 +164,13 @@ def main():
     for k in range(args.steps):
         i = args.warmup + k
         name, pos, f, u, r = cams[i % len(cams)]
-        ctx.RenderScreen(W, H, frame if world == 1 else local, pos, f, u, r, opts(i + 1, stats=True))
+        ctx.RenderScreen(W, H, frame if world == 1 else local, pos, f, u, r, opts(i + 1, stats=True))  # `local`: scratch
     sp = ctx.frame_stats()
     assert sp.total_rays() == rays_local, "ray counts differ between the timed and the counting pass"
     bytes_local = sp.algorithmic_bytes()
 
-    tot = torch.tensor([float(rays_local), float(bytes_local), float(sum(kernel_ms))], dtype=torch.float64, device=dev)
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(rays_local), float(bytes_local), float(sum(kernel_ms))], dtype=torch.float64, device=red_dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -191,6 +212,17 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
                          "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1)},
         }
+        if rehearse:  # the gathered frame of the last step must equal a single-GPU render of the same frame
+            i = args.warmup + args.steps - 1
+            name, pos, f, u, r = cams[i % len(cams)]
+            full = torch.zeros_like(frame)
+            ctx.RenderScreen(W, H, full, pos, f, u, r, vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,
+                                                                   bounce_all_hits=bool(args.bounce_all_hits),
+                                                                   frame_number=i + 1))
+            torch.cuda.synchronize()
+            result["rehearsal"] = {"gathered_frame_equals_single_gpu_frame": bool(torch.equal(full, frame)),
+                                   "note": "all ranks on one GPU over gloo: value is not a measurement"}
+            ctx.frame_stats()
         if args.cpu_baseline == "auto" and world == 1:
             result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts)
     if world > 1:

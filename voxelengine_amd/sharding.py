@@ -55,6 +55,63 @@ class ShardPlan:
         return (local_row // self.strip_rows * self.world_size + rank) * self.strip_rows + local_row % self.strip_rows
 
 
+class GatherPipeline:
+    """Two-deep pipeline of frames: the gather of frame k runs (on RCCL's stream) while frame k+1 is rendered.
+
+    Per frame: ``buf = pipe.local(k)`` -> render into it -> ``pipe.submit(k)``.  The root de-interleaves frame k-1
+    inside ``submit(k)``; ``pipe.flush()`` completes the last frame.  Each rank owns two packed shard buffers,
+    the root two gather buffers, so a buffer is reused only after the collective that read it has completed
+    (``work.wait()`` orders the stream, it does not block the host for NCCL).
+    """
+
+    def __init__(self, plan: ShardPlan, make_buffer, frame_on_root, deinterleave, group=None):
+        self.plan, self.frame, self.deinterleave, self.group = plan, frame_on_root, deinterleave, group
+        self.locals = [make_buffer(plan.shard_bytes) for _ in range(2)]
+        self.shards = [make_buffer(plan.world_size * plan.shard_bytes).view(plan.world_size, plan.shard_bytes)
+                       for _ in range(2)] if plan.rank == 0 else [None, None]
+        self.works = [None, None]
+        self.pending = None  # frame index gathered but not yet de-interleaved on the root
+
+    def local(self, k: int):
+        b = k & 1
+        if self.works[b] is not None:  # the gather issued two frames ago read this buffer
+            self.works[b].wait()
+            self.works[b] = None
+        return self.locals[b]
+
+    def submit(self, k: int):
+        import torch.distributed as dist
+
+        b = k & 1
+        p = self.plan
+        if p.rank == 0:
+            self.works[b] = dist.gather(self.locals[b], [self.shards[b][r] for r in range(p.world_size)], dst=0,
+                                        group=self.group, async_op=True)
+        else:
+            self.works[b] = dist.gather(self.locals[b], None, dst=0, group=self.group, async_op=True)
+        self._finish(k - 1)
+        self.pending = k
+
+    def _finish(self, k: int):
+        if self.pending is None or self.pending != k:
+            return
+        b = k & 1
+        if self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+        if self.plan.rank == 0:
+            self.deinterleave(self.shards[b], self.frame)
+        self.pending = None
+
+    def flush(self):
+        if self.pending is not None:
+            self._finish(self.pending)
+        for b in range(2):
+            if self.works[b] is not None:
+                self.works[b].wait()
+                self.works[b] = None
+
+
 def gather_frame(plan: ShardPlan, local_shard, shards_on_root, frame_on_root, deinterleave, group=None):
     """Gather the packed shard buffers to rank 0 and rebuild the frame there.
 
