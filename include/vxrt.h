@@ -45,9 +45,10 @@ int vxrt_destroy(vxrt_ctx *ctx);
 /* message of the last failing call on this thread (never NULL) */
 const char *vxrt_last_error(void);
 int vxrt_synchronize(vxrt_ctx *ctx);
-/* kernel implementation used by vxrt_render / vxrt_trace_batch: 0 = wave-level state machine (default),
- * 1 = straightforward per-lane loops.  Both give identical results; 1 exists for A/B timing and as an
- * on-device cross-check. */
+/* kernel implementation used by vxrt_render / vxrt_trace_batch: 2 = persistent waves pulling pixels from a tile
+ * queue (default; the batch trace uses the wave-level state machine), 0 = wave-level state machine with one lane
+ * per pixel, 1 = straightforward per-lane loops.  All give identical results; 0 and 1 exist for A/B timing and
+ * as on-device cross-checks. */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 
 /* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,

@@ -3,7 +3,7 @@ the oracle cannot render whole frames in test time: size-independent properties 
   * a random sample of the frame's primary rays: HIP batch trace == oracle (bit-exact), on the downloaded bricks
   * the two entry points agree: hit voxel AOV of vxrt_render == vxrt_trace_batch of the same camera rays
   * idempotence: the same frame rendered twice is byte-identical
-  * the two independent kernel implementations (variant 0 / 1) produce the same frame
+  * the three separately written kernels (variants 0, 1, 2) produce the same frame
   * 8 interleaved strip shards reassemble into the single-GPU frame
   * ray accounting: shadow rays == primary hits; rays <= 3 * pixels
 """
@@ -111,14 +111,16 @@ def test_idempotence_variants_and_strip_shards(big):
     ctx.RenderScreen(W, H, b, pos, fwd, up, right, vx.RenderOptions(**base))
     torch.cuda.synchronize()
     assert torch.equal(a, b)
-    ctx.set_kernel_variant(1)
+    default = ctx.kernel_variant
     try:
-        b.zero_()
-        ctx.RenderScreen(W, H, b, pos, fwd, up, right, vx.RenderOptions(**base))
-        torch.cuda.synchronize()
-        assert torch.equal(a, b)
+        for variant in (0, 1, 2):  # three separately written kernels, one frame
+            ctx.set_kernel_variant(variant)
+            b.zero_()
+            ctx.RenderScreen(W, H, b, pos, fwd, up, right, vx.RenderOptions(**base))
+            torch.cuda.synchronize()
+            assert torch.equal(a, b), variant
     finally:
-        ctx.set_kernel_variant(0)
+        ctx.set_kernel_variant(default)
     count, rows = 8, 16
     max_rows = max(vx.compact_rows(H, rows, count, i) for i in range(count))
     stride = max_rows * W * 4

@@ -50,7 +50,7 @@ struct vxrt_ctx {
     float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
     float ortho[2] = {10.0f, 10.0f};
     uint32_t frame_counter = 0;
-    int kernel_variant = 0;          // 0 = wave state machine, 1 = straightforward loops, 2 = persistent waves
+    int kernel_variant = 2;          // render: 2 = persistent waves (default), 0 = wave state machine, 1 = straightforward
     unsigned persistent_waves = 4096;
     unsigned long long* d_stats = nullptr;
 };

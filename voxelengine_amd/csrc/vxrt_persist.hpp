@@ -80,7 +80,7 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, int x, int y, f3
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
+__global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
 {
     const WorldView& W = A.W;
     const int lane = threadIdx.x & 63;
@@ -105,11 +105,10 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
     const f3 L = A.light_dir;
     const f3 sray = unit3(L);
 
-    auto store_pixel = [&](const PixelCoords& pc, bool hit, f3 normal, f3 pos, f3 shaded) {
+    // store one finished pixel (setPixelColor + the debug overlays of screenDispatch, Renderer.cu:213-275)
+    auto store_pixel = [&](const PixelCoords& pc, f3 origin, f3 ray, bool hit, f3 normal, f3 pos, f3 shaded) {
         PixelSink sink{A, pc.out_row};
         const int Wd = (int)A.width, Hd = (int)A.height;
-        f3 origin, ray;
-        camera_ray(A, pc.x, pc.y, origin, ray);
         if (hit) {
             if (A.mode == 1) {  // DEBUG_VIEW quadrants, Renderer.cu:215-243
                 f3 dv = pos - origin;
@@ -137,18 +136,6 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
             sink.put(pc.x, pc.y, mk3((float)p_steps / 256.0f, 0, 0));
     };
 
-    auto begin_bounce = [&](const PixelCoords& pc, f3 normal, int i) {  // one sample of Renderer.cu:128-142
-        const uint32_t seed = pc.ty * A.width + pc.tx;
-        const uint32_t si = seed + (uint32_t)i * 1000u + (A.frame_number + 1u) * 1000u;
-        f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
-        sd = unit3(sd);
-        if (dot3(sd, normal) < 0)
-            sd = reflect3(sd, normal);
-        n_bounce += 1;
-        T.begin_ray(W, position + normal * 0.01f, sd, 8);
-        stage = PX_BOUNCE;
-    };
-
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
@@ -159,13 +146,20 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end), n_next = __popcll(m_next);
 
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
+        // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
+        // launch; one begin_ray at the end of the phase serves them all (its 7 divisions + square root are the
+        // expensive part of this phase).
         if (vote_run(n_next, n_walk + n_box + n_end)) {
+            bool launch = false;
+            f3 l_origin = mk3(0, 0, 0), l_dir = mk3(1, 0, 0);
+            int l_max = kMaxSteps;
             if (T.st == ST_DONE && stage != PX_NONE) {
                 const PixelCoords pc = pixel_coords(A, px_tx, px_row);
+                f3 origin, ray;
+                camera_ray(A, pc.x, pc.y, origin, ray);
                 TraceResult r;
                 T.result(W, r);
-                bool finalize = false, do_shade = false, shadowed = false;
-                f3 normal;
+                bool finalize = false, do_shade = false, shadowed = false, bounce = false;
                 if (stage == PX_PRIMARY) {
                     pcode = (r.hit && r.steps == 0) ? T.entry_code : T.out_code;
                     p_steps = r.steps;
@@ -180,7 +174,10 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
                         finalize = true;
                     } else if (A.shadow) {
                         n_shadow += 1;
-                        T.begin_ray(W, position + sray * 0.01f, sray, kMaxSteps);  // Renderer.cu:97-102
+                        launch = true;  // Renderer.cu:97-102
+                        l_origin = position + sray * 0.01f;
+                        l_dir = sray;
+                        l_max = kMaxSteps;
                         stage = PX_SHADOW;
                     } else {
                         do_shade = true;
@@ -189,13 +186,9 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
                     shadowed = r.hit;
                     do_shade = true;
                 }
-                {
-                    const f3 pn = normal_decode(pcode);
-                    normal = mk3(-pn.x, -pn.y, -pn.z);  // Renderer.cu:212
-                }
+                const f3 pn = normal_decode(pcode);
+                const f3 normal = mk3(-pn.x, -pn.y, -pn.z);  // Renderer.cu:212
                 if (do_shade) {  // calculateColor, Renderer.cu:104-118
-                    f3 origin, ray;
-                    camera_ray(A, pc.x, pc.y, origin, ray);
                     const float l_dot = hi(dot3(normal, L), 0) * (float)(shadowed ? 0 : 1);
                     f3 diffuse = A.light_color * l_dot;
                     float up_dot = normal.x * 0.0f + normal.y * 1.0f + normal.z * 0.0f;
@@ -209,26 +202,20 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
                         color.y += spec * A.light_color.y;
                         color.z += spec * A.light_color.z;
                     }
-                    if (l_dot == 0 || A.bounce_all_hits) {  // Renderer.cu:121
+                    stage = PX_PRIMARY;
+                    if ((l_dot == 0 || A.bounce_all_hits) && A.bounce_samples > 0) {  // Renderer.cu:121
                         occl = 0.0f;
                         sample = 0;
-                        if (A.bounce_samples > 0) {
-                            begin_bounce(pc, normal, 0);
-                        } else {
-                            color = color * 1.0f;  // samples == 0: occlusion = 1 (Renderer.cu:159-164)
-                            stage = PX_PRIMARY;
-                            finalize = true;
-                        }
+                        bounce = true;
                     } else {
-                        stage = PX_PRIMARY;
-                        finalize = true;
+                        finalize = true;  // gate closed, or samples == 0: occlusion = 1 (Renderer.cu:159-164)
                     }
-                } else if (stage == PX_BOUNCE && T.st == ST_DONE) {
+                } else if (stage == PX_BOUNCE) {
                     if (!r.hit)
                         occl += 1.0f;
                     sample += 1;
                     if (sample < A.bounce_samples) {
-                        begin_bounce(pc, normal, sample);
+                        bounce = true;
                     } else {
                         occl /= (float)A.bounce_samples;
                         color = color * occl;
@@ -236,12 +223,27 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
                         finalize = true;
                     }
                 }
+                if (bounce) {  // one sample of Renderer.cu:128-142
+                    const uint32_t seed = pc.ty * A.width + pc.tx;
+                    const uint32_t si = seed + (uint32_t)sample * 1000u + (A.frame_number + 1u) * 1000u;
+                    f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
+                    sd = unit3(sd);
+                    if (dot3(sd, normal) < 0)
+                        sd = reflect3(sd, normal);
+                    n_bounce += 1;
+                    launch = true;
+                    l_origin = position + normal * 0.01f;
+                    l_dir = sd;
+                    l_max = 8;
+                    stage = PX_BOUNCE;
+                }
                 if (finalize) {
-                    store_pixel(pc, stage != PX_NONE, normal, position, color);
+                    store_pixel(pc, origin, ray, stage != PX_NONE, normal, position, color);
                     stage = PX_NONE;
                 }
             }
             // hand out pixels of the wave's tile(s) to the lanes that are free
+            bool got = false;
             unsigned long long want = __ballot(T.st == ST_DONE && stage == PX_NONE);
             while (want != 0ull && !drained) {
                 if (tile_used >= 64u) {
@@ -262,19 +264,22 @@ __global__ __launch_bounds__(64) void k_render_persist(RenderArgs A)
                     const uint32_t p = tile_used + rank;
                     px_tx = (tile % ntx) * 8u + (p & 7u);
                     px_row = (tile / ntx) * 8u + (p >> 3);
-                    const PixelCoords pc = pixel_coords(A, px_tx, px_row);
-                    if (pc.live) {
-                        f3 origin, ray;
-                        camera_ray(A, pc.x, pc.y, origin, ray);
-                        n_primary += 1;
-                        T.begin_ray(W, origin, ray, kMaxSteps);
-                        stage = PX_PRIMARY;
-                    }
+                    got = pixel_coords(A, px_tx, px_row).live;
                 }
                 const uint32_t asked = (uint32_t)__popcll(want);
                 tile_used += asked < avail ? asked : avail;
-                want = __ballot(T.st == ST_DONE && stage == PX_NONE);
+                want = __ballot(T.st == ST_DONE && stage == PX_NONE && !got);
             }
+            if (got) {
+                const PixelCoords pc = pixel_coords(A, px_tx, px_row);
+                camera_ray(A, pc.x, pc.y, l_origin, l_dir);
+                l_max = kMaxSteps;
+                n_primary += 1;
+                launch = true;
+                stage = PX_PRIMARY;
+            }
+            if (launch)
+                T.begin_ray(W, l_origin, l_dir, l_max);
             if (drained && T.st == ST_DONE && stage == PX_NONE)
                 T.st = ST_IDLE;
         }

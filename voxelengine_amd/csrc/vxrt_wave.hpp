@@ -63,6 +63,8 @@ struct WaveTracer {
     uint32_t st, fine, wf, w_code, skip;
     f3 ws, point;
     int cell_x, cell_y, cell_z, lim_x, lim_y, lim_z;
+    int dm1_x, dm1_y, dm1_z, tw, twh;  // per-walk level constants kept in registers: dimension-1, tiles per row/slice
+    int up_x, up_y, up_z;              // per-ray: 1 where the direction component is positive (:195-197)
     float tn_x, tn_y, tn_z;
     int steps;  // stepsTaken; also the reference's loop index: an iteration continues exactly when a step is counted
     // coarse results kept across the brick walk
@@ -86,6 +88,11 @@ struct WaveTracer {
         ray_hit = false;
         cell_x = cell_y = cell_z = 0;
         lim_x = lim_y = lim_z = 0;
+        dm1_x = dm1_y = dm1_z = 0;
+        tw = W.ctw;
+        twh = W.ctwh;
+        up_x = 1;
+        up_y = up_z = 0;
         tn_x = tn_y = tn_z = 0.0f;
         steps = 0;
         chx = chy = chz = nc_axis = 0;
@@ -118,9 +125,9 @@ struct WaveTracer {
         cell_x = (int)s.x;
         cell_y = (int)s.y;
         cell_z = (int)s.z;
-        tn_x = d.x != 0 ? ((float)(cell_x + (d.x > 0 ? 1 : 0)) - s.x) / d.x : kInf;
-        tn_y = d.y != 0 ? ((float)(cell_y + (d.y > 0 ? 1 : 0)) - s.y) / d.y : kInf;
-        tn_z = d.z != 0 ? ((float)(cell_z + (d.z > 0 ? 1 : 0)) - s.z) / d.z : kInf;
+        tn_x = d.x != 0 ? ((float)(cell_x + up_x) - s.x) / d.x : kInf;
+        tn_y = d.y != 0 ? ((float)(cell_y + up_y) - s.y) / d.y : kInf;
+        tn_z = d.z != 0 ? ((float)(cell_z + up_z) - s.z) / d.z : kInf;
         point = s;
         steps = 0;
         wf = 0u;
@@ -133,6 +140,11 @@ struct WaveTracer {
         lim_x = dmx + ((edge && d.x < 0) ? 1 : 0);
         lim_y = dmy + ((edge && d.y < 0) ? 1 : 0);
         lim_z = dmz + ((edge && d.z < 0) ? 1 : 0);
+        dm1_x = dmx - 1;
+        dm1_y = dmy - 1;
+        dm1_z = dmz - 1;
+        tw = to_fine ? W.ftw : W.ctw;
+        twh = to_fine ? W.ftwh : W.ctwh;
     }
 
     // Raytrace's prologue (:359-384): per-ray constants, world entry, first coarse walk
@@ -146,6 +158,9 @@ struct WaveTracer {
         tdy = d.y != 0 ? fabsf(ivy) : kInf;
         tdz = d.z != 0 ? fabsf(ivz) : kInf;
         max_steps = max_steps_;
+        up_x = d.x > 0 ? 1 : 0;
+        up_y = d.y > 0 ? 1 : 0;
+        up_z = d.z > 0 ? 1 : 0;
         start = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
         entry_code = 0u;
         if (!(start.x >= 0 && start.y >= 0 && start.z >= 0 && start.x < (float)W.cx && start.y < (float)W.cy &&
@@ -251,38 +266,37 @@ struct WaveTracer {
         f3 bp;
         uint32_t bc;
         const bool box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
-        if (box_hit) {
-            wf = WF_HIT;
-            if (steps != 0)  // `step != 0`, :266
-                point = bp;
-            chx = qx;
-            chy = qy;
-            chz = qz;
-            c_code = bc;
-            slot = meta.x;
-            // the exit iteration's extra advance (:290-322) only matters through NextCell's axis
-            nc_axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
-            st = ST_END;
-        } else {
-            skip = 1u;  // not a hit: walk on without probing this cell again
-            st = ST_WALK;
-        }
+        // All updates as selects.  (Written as `if (hit) { wf = 1; ... } else { skip = 1; }` the optimiser merges
+        // the two stores of the constant 1 into ONE store through a selected address, which demotes these members
+        // from registers to scratch memory -- seen as scratch_store/scratch_load inside the hot loop.)
+        wf = box_hit ? (uint32_t)WF_HIT : wf;
+        skip = box_hit ? 0u : 1u;  // not a hit: walk on without probing this cell again
+        st = box_hit ? (uint32_t)ST_END : (uint32_t)ST_WALK;
+        const bool move_point = box_hit && steps != 0;  // `step != 0`, :266
+        point.x = move_point ? bp.x : point.x;  // per component: a struct-valued ?: selects an ADDRESS (same trap)
+        point.y = move_point ? bp.y : point.y;
+        point.z = move_point ? bp.z : point.z;
+        chx = box_hit ? qx : chx;
+        chy = box_hit ? qy : chy;
+        chz = box_hit ? qz : chz;
+        c_code = box_hit ? bc : c_code;
+        slot = box_hit ? meta.x : slot;
+        // the exit iteration's extra advance (:290-322) only matters through NextCell's axis
+        const int axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
+        nc_axis = box_hit ? axis : nc_axis;
     }
 
     // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane
     __device__ __forceinline__ void step(const WorldView& W)
     {
         const uint32_t w = (st == ST_WALK) ? 1u : 0u;
-        const bool is_fine = fine != 0u;
-        const int dm1x = is_fine ? W.f - 1 : W.cx - 1, dm1y = is_fine ? W.f - 1 : W.cy - 1,
-                  dm1z = is_fine ? W.f - 1 : W.cz - 1;
         // 0 <= cell < dim + pad on all three axes, as one sign test: every (cell - lim) negative, no cell negative
         const int in_bits = (cell_x - lim_x) & (cell_y - lim_y) & (cell_z - lim_z) & ~(cell_x | cell_y | cell_z);
         const uint32_t in = (uint32_t)in_bits >> 31;
         // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); an out-of-range
         // lane reads word 0 instead, so the unconditional load below always has a valid address
-        const int qx = min(cell_x, dm1x), qy = min(cell_y, dm1y), qz = min(cell_z, dm1z);
-        const uint32_t idx_raw = tiled_index(qx, qy, qz, is_fine ? W.ftw : W.ctw, is_fine ? W.ftwh : W.ctwh);
+        const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
+        const uint32_t idx_raw = tiled_index(qx, qy, qz, tw, twh);
         const uint32_t idx = in ? idx_raw : 0u;
         const uint32_t word = bits[idx >> 5];
         const uint32_t solid = (word >> (idx & 31u)) & 1u & ~skip;
@@ -298,28 +312,30 @@ struct WaveTracer {
         skip = skip & (w ^ 1u);
 
         // DDA advance (:293-322), computed for every lane, committed where adv
-        const bool upx = d.x > 0, upy = d.y > 0, upz = d.z > 0;
         const bool lt_xy = tn_x < tn_y, lt_xz = tn_x < tn_z, lt_yz = tn_y < tn_z;
         const bool ax0 = lt_xy && lt_xz;
         const bool ax1 = !lt_xy && lt_yz;  // tn_y <= tn_x && tn_y < tn_z; implies !ax0
         const float t = ax0 ? tn_x : (ax1 ? tn_y : tn_z);
-        const float crx = ax0 ? (float)(cell_x + (upx ? 1 : 0)) : ws.x + (t * d.x);
-        const float cry = ax1 ? (float)(cell_y + (upy ? 1 : 0)) : ws.y + (t * d.y);
-        const float crz = (ax0 || ax1) ? ws.z + (t * d.z) : (float)(cell_z + (upz ? 1 : 0));
+        const float crx = ax0 ? (float)(cell_x + up_x) : ws.x + (t * d.x);
+        const float cry = ax1 ? (float)(cell_y + up_y) : ws.y + (t * d.y);
+        const float crz = (ax0 || ax1) ? ws.z + (t * d.z) : (float)(cell_z + up_z);
         // region check on the crossing point, brick walks only (:325-341): [0,f]^3, step not counted
         const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
         const uint32_t region_oob = ((cmin < 0.0f || cmax > W.ff) ? 1u : 0u) & fine & adv;
         const uint32_t ok = adv & (region_oob ^ 1u);
         const bool commit = adv != 0u, counted = ok != 0u;
-        cell_x += (commit && ax0) ? (upx ? 1 : -1) : 0;
-        cell_y += (commit && ax1) ? (upy ? 1 : -1) : 0;
-        cell_z += (commit && !ax0 && !ax1) ? (upz ? 1 : -1) : 0;
+        cell_x += (commit && ax0) ? 2 * up_x - 1 : 0;
+        cell_y += (commit && ax1) ? 2 * up_y - 1 : 0;
+        cell_z += (commit && !ax0 && !ax1) ? 2 * up_z - 1 : 0;
         tn_x = (commit && ax0) ? tn_x + tdx : tn_x;
         tn_y = (commit && ax1) ? tn_y + tdy : tn_y;
         tn_z = (commit && !ax0 && !ax1) ? tn_z + tdz : tn_z;
-        const uint32_t code = ax0 ? (1u | (upx ? 0u : 4u)) : (ax1 ? (2u | (upy ? 0u : 4u)) : (3u | (upz ? 0u : 4u)));
+        // normal code (axis+1) | 4*negative = axis + 5 - 4*up
+        const uint32_t code = ax0 ? (uint32_t)(5 - 4 * up_x) : (ax1 ? (uint32_t)(6 - 4 * up_y) : (uint32_t)(7 - 4 * up_z));
         w_code = counted ? code : w_code;
-        point = counted ? mk3(crx, cry, crz) : point;
+        point.x = counted ? crx : point.x;
+        point.y = counted ? cry : point.y;
+        point.z = counted ? crz : point.z;
         steps += (int)ok;
         const uint32_t exhausted = ok & (steps >= kMaxSteps ? 1u : 0u);  // walk ran out of iterations (:234)
         wf |= leave_hit * WF_HIT | (leave_oob | region_oob) * WF_OOB;

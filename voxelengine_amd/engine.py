@@ -59,7 +59,7 @@ class Context:
         N.check(self._L.vxrt_create(device, C.byref(h)))
         self._h = h
         self.device = device
-        self.kernel_variant = 0
+        self.kernel_variant = 2  # the library's default (persistent waves)
 
     def close(self):
         if getattr(self, "_h", None):
