@@ -107,6 +107,20 @@ int vxo_ray_aabb(const float start[3], const float dir[3], const float bmin[3], 
 
 /* ------------------------------------------------------------ single-level DDA */
 
+/* float -> int as the GPUs the reference targets do it (cvt.rzi / v_cvt_i32_f32): truncation that SATURATES, NaN -> 0.
+ * C leaves out-of-range conversions undefined (x86 yields INT_MIN); rays with infinite or huge intermediate
+ * positions (denormal direction components make 1/d overflow) reach such conversions, so the definition matters. */
+static inline int sat_i32(float v)
+{
+    if (!(v == v))
+        return 0;
+    if (v >= 2147483648.0f)
+        return 2147483647;
+    if (v <= -2147483648.0f)
+        return (-2147483647 - 1);
+    return (int)v;
+}
+
 /* min(max(v, lo), hi) exactly as written at VolumeRaytracer.cu:242-244 */
 static inline int clampi(int v, int lo_, int hi_)
 {
@@ -135,10 +149,10 @@ void vxo_dda(const vxo_dda_params *p, vxo_dda_result *r)
     int cell[3], sgn[3], pad[3] = {0, 0, 0};
     float t_delta[3], t_next[3];
     for (int a = 0; a < 3; ++a) {
-        cell[a] = (int)s[a];
+        cell[a] = sat_i32(s[a]);
         sgn[a] = (d[a] > 0) ? 1 : -1;
         t_delta[a] = (d[a] != 0) ? fabsf(1.0f / d[a]) : VXO_INF;
-        t_next[a] = (d[a] != 0) ? (((float)(cell[a] + (sgn[a] > 0)) - s[a]) / d[a]) : VXO_INF;
+        t_next[a] = (d[a] != 0) ? (((float)(int)((unsigned)cell[a] + (unsigned)(sgn[a] > 0)) - s[a]) / d[a]) : VXO_INF;
     }
     memset(r, 0, sizeof(*r));
     for (int a = 0; a < 3; ++a)
@@ -208,8 +222,8 @@ void vxo_dda(const vxo_dda_params *p, vxo_dda_result *r)
         float t = t_next[axis];
         float crossing[3];
         for (int a = 0; a < 3; ++a)
-            crossing[a] = (a == axis) ? (float)(cell[a] + (sgn[a] > 0)) : s[a] + (t * d[a]);
-        cell[axis] += sgn[axis];
+            crossing[a] = (a == axis) ? (float)(int)((unsigned)cell[a] + (unsigned)(sgn[a] > 0)) : s[a] + (t * d[a]);
+        cell[axis] = (int)((unsigned)cell[axis] + (unsigned)sgn[axis]);  /* wraps like the hardware add */
         t_next[axis] += t_delta[axis];
 
         if (leaving) {
@@ -352,15 +366,15 @@ int vxo_raytrace(const vxo_world *w, int max_steps, const float origin[3], const
         if (br.out_of_bounds) {
             int same = 1;
             for (int a = 0; a < 3; ++a)
-                same = same && cr.hit_cell[a] == (float)(int)start[a];
+                same = same && cr.hit_cell[a] == (float)sat_i32(start[a]);
             if (same) {
                 for (int a = 0; a < 3; ++a) {
-                    if (cr.hit_cell[a] == (float)(int)start[a])
+                    if (cr.hit_cell[a] == (float)sat_i32(start[a]))
                         start[a] = step_ulp(start[a], dir[a]);
                 }
                 same = 1;
                 for (int a = 0; a < 3; ++a)
-                    same = same && cr.hit_cell[a] == (float)(int)start[a];
+                    same = same && cr.hit_cell[a] == (float)sat_i32(start[a]);
                 if (same) {
                     float gap[3], mag[3];
                     for (int a = 0; a < 3; ++a) {

@@ -35,7 +35,29 @@ def mixed_rays(dims, n, seed=0):
     c = np.array([X, Y, Z], np.float32) / 2
     aim = slice(k, k + k // 2)
     d[aim] = (c + rng.normal(size=(k // 2, 3)).astype(np.float32) * c * 0.5) - o[aim]
-    bad = (np.abs(d).sum(axis=1) == 0)
+    # adversarial families (every 13th/17th/... ray): tiny and denormal direction components, far-away origins
+    # aimed at the grid, axis-aligned rays running exactly along cell boundaries
+    idx = np.arange(n)
+    m = idx % 13 == 0
+    d[m, (idx[m] // 13) % 3] *= np.float32(1e-30)
+    m = idx % 17 == 0
+    d[m, (idx[m] // 17) % 3] = np.float32(1e-42)
+    m = idx % 23 == 0
+    o[m] = o[m] * np.float32(1000.0)
+    d[m] = c - o[m]
+    m = idx % 31 == 0                                 # exact x/y ties entering through a grid corner / far faces
+    o[m, 0] = o[m, 1] = np.float32(X) * (1.5 + (idx[m] % 7)).astype(np.float32)
+    d[m, 0] = d[m, 1] = -np.abs(d[m, 0]) - np.float32(0.1)
+    m = idx % 37 == 0
+    o[m, 1] = o[m, 2] = np.float32(-0.5 * Y)
+    d[m, 1] = d[m, 2] = np.abs(d[m, 1]) + np.float32(0.1)
+    m = idx % 29 == 0
+    d[m] = 0
+    d[m, 0] = np.where(idx[m] & 1, 1.0, -1.0).astype(np.float32)
+    o[m, 1:] = np.floor(o[m, 1:])
+    # a direction whose squared length underflows normalises to inf/NaN: not a ray (and float->int of NaN is
+    # where host C and GPUs legitimately differ), so keep at least one ordinary component
+    bad = (np.abs(d).max(axis=1) < 1e-10)
     d[bad] = (1, 0, 0)
     return o, d
 

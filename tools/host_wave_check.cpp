@@ -36,6 +36,15 @@ int main(int argc, char** argv)
         for (int a = 0; a < 3; ++a) { o[a] = (rand() / (float)RAND_MAX) * (i % 3 ? S : 3 * S) - (i % 3 ? 0 : S); d[a] = rand() / (float)RAND_MAX * 2 - 1; }
         if (i % 7 == 0) d[i % 3] = 0;
         if (i % 11 == 0) { o[0] = floorf(o[0]); o[1] = floorf(o[1]); }
+        // adversarial families: tiny / denormal direction components, starts exactly on the far faces (edge rule),
+        // far-away origins aimed at the grid, axis-aligned rays along cell boundaries
+        if (i % 13 == 0) d[(i / 13) % 3] *= 1e-30f;
+        if (i % 17 == 0) d[(i / 17) % 3] = 1e-42f;
+        if (i % 19 == 0) { o[(i / 19) % 3] = (float)S; d[(i / 19) % 3] = -fabsf(d[(i / 19) % 3]) - 0.01f; }
+        if (i % 23 == 0) { for (int a = 0; a < 3; ++a) { o[a] = o[a] * 1000.0f; d[a] = S * 0.5f - o[a]; } }
+        if (i % 31 == 0) { o[0] = o[1] = S * (1.5f + (i % 7)); d[0] = d[1] = -fabsf(d[0]) - 0.1f; }  // exact x/y ties through a grid corner
+        if (i % 37 == 0) { o[1] = o[2] = -S * 0.5f; d[1] = d[2] = fabsf(d[1]) + 0.1f; }
+        if (i % 29 == 0) { d[0] = (i & 1) ? 1.0f : -1.0f; d[1] = d[2] = 0; o[1] = floorf(o[1]); o[2] = floorf(o[2]); }
         int steps; float nn[3], pp[3] = {0, 0, 0}; int vox[3] = {0, 0, 0}; vxo_ray_stats st{};
         int h = vxo_raytrace(w, 2048, o, d, &steps, nn, pp, vox, &st);
         TraceResult t; RayCounters c{0, 0, 0};

@@ -19,5 +19,6 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static inline int __float2int_rz(float v) { if (!(v == v)) return 0; if (v >= 2147483648.0f) return 2147483647; if (v <= -2147483648.0f) return (-2147483647 - 1); return (int)v; }
 using std::min;
 using std::max;

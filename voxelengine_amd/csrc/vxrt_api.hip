@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -510,6 +511,12 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     B.hit = d_hit;
     B.voxel = (long long*)d_voxel;
     B.stats = c->d_stats;
+    unsigned int* d_dbg = nullptr;
+    if (stats && getenv("VXRT_DEBUG_TRACE")) {  // development: dump the wave loop's view of ray 0
+        VX_HIP(hipMalloc((void**)&d_dbg, 400 * 12 * 4));
+        VX_HIP(hipMemset(d_dbg, 0xFF, 400 * 12 * 4));
+        B.dbg_trace = d_dbg;
+    }
     if (stats) {  // a stats request reports this batch alone
         VX_HIP(hipDeviceSynchronize());
         VX_HIP(hipMemset(c->d_stats, 0, vxrt::kStatCount * sizeof(unsigned long long)));
@@ -518,6 +525,19 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     VX_HIP(hipGetLastError());
     if (stats) {
         VX_HIP(hipStreamSynchronize(stream));
+        if (d_dbg) {
+            std::vector<unsigned int> h(400 * 12);
+            VX_HIP(hipMemcpy(h.data(), d_dbg, h.size() * 4, hipMemcpyDeviceToHost));
+            (void)hipFree(d_dbg);
+            for (int it = 0; it < 400 && h[it * 12] != 0xFFFFFFFFu; ++it) {
+                const unsigned int* r = &h[it * 12];
+                float tn[3], ws[2];
+                memcpy(tn, r + 5, 12);
+                memcpy(ws, r + 10, 8);
+                fprintf(stderr, "it %d st=%u fine=%u cell=(%d,%d,%d) tn=(%.9g,%.9g,%.9g) steps=%d total=%d ws=(%.9g,%.9g)\n", it, r[0], r[1],
+                        (int)r[2], (int)r[3], (int)r[4], tn[0], tn[1], tn[2], (int)r[8], (int)r[9], ws[0], ws[1]);
+            }
+        }
         return vxrt_frame_stats_get(c, stats);
     }
     return VXRT_OK;

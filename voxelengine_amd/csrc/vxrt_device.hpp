@@ -60,6 +60,10 @@ struct RayCounters {
     uint32_t iters = 0, walk_lanes = 0, end_runs = 0, box_runs = 0;
 };
 
+// float -> int as the hardware does it (v_cvt_i32_f32): truncation, saturating, NaN -> 0.  Spelled with the
+// intrinsic because a C cast is undefined out of range, and such values do occur (1/d overflows for denormal d).
+__device__ __forceinline__ int f2i(float v) { return __float2int_rz(v); }
+
 // 8x8x8 tiled-linear bit address (GetSampleIndex, VolumeRaytracer.cuh:107-131)
 __device__ __forceinline__ uint32_t tiled_index(int x, int y, int z, int tw, int twh)
 {
@@ -127,7 +131,7 @@ template <bool COARSE>
 __device__ void walk_level(const WorldView& W, const uint32_t* __restrict__ bits, int dim_x, int dim_y, int dim_z,
                            int tw, int twh, f3 s, f3 d, WalkResult& R, uint32_t& probes)
 {
-    int cell_x = (int)s.x, cell_y = (int)s.y, cell_z = (int)s.z;
+    int cell_x = f2i(s.x), cell_y = f2i(s.y), cell_z = f2i(s.z);
     const int sgn_x = d.x > 0 ? 1 : -1, sgn_y = d.y > 0 ? 1 : -1, sgn_z = d.z > 0 ? 1 : -1;
     const float td_x = d.x != 0 ? fabsf(1.0f / d.x) : kInf;
     const float td_y = d.y != 0 ? fabsf(1.0f / d.y) : kInf;
@@ -300,12 +304,12 @@ __device__ void trace_direct(const WorldView& W, int max_steps, f3 origin, f3 ra
         }
         start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
         if (b.oob) {
-            bool same = hx == (float)(int)start.x && hy == (float)(int)start.y && hz == (float)(int)start.z;
+            bool same = hx == (float)f2i(start.x) && hy == (float)f2i(start.y) && hz == (float)f2i(start.z);
             if (same) {
                 start.x = ulp_step(start.x, dir.x < 0);
                 start.y = ulp_step(start.y, dir.y < 0);
                 start.z = ulp_step(start.z, dir.z < 0);
-                same = hx == (float)(int)start.x && hy == (float)(int)start.y && hz == (float)(int)start.z;
+                same = hx == (float)f2i(start.x) && hy == (float)f2i(start.y) && hz == (float)f2i(start.z);
                 if (same) {
                     float gx = (float)c.ncx - start.x, gy = (float)c.ncy - start.y, gz = (float)c.ncz - start.z;
                     float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);

@@ -53,6 +53,7 @@ struct BatchArgs {
     uint8_t* hit;
     long long* voxel;
     unsigned long long* stats;
+    unsigned int* dbg_trace;  // development: per-iteration state of ray 0 (probe-counting variant only), or NULL
 };
 
 }  // namespace vxrt

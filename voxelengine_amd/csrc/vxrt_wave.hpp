@@ -122,9 +122,9 @@ struct WaveTracer {
     {
         fine = to_fine;
         ws = s;
-        cell_x = (int)s.x;
-        cell_y = (int)s.y;
-        cell_z = (int)s.z;
+        cell_x = f2i(s.x);
+        cell_y = f2i(s.y);
+        cell_z = f2i(s.z);
         tn_x = d.x != 0 ? ((float)(cell_x + up_x) - s.x) / d.x : kInf;
         tn_y = d.y != 0 ? ((float)(cell_y + up_y) - s.y) / d.y : kInf;
         tn_z = d.z != 0 ? ((float)(cell_z + up_z) - s.z) / d.z : kInf;
@@ -217,15 +217,19 @@ struct WaveTracer {
             } else {  // brick missed: restart the coarse walk just past it (:431-491)
                 start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
                 if (wf & WF_OOB) {
-                    bool same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
+                    bool same = fx == (float)f2i(start.x) && fy == (float)f2i(start.y) && fz == (float)f2i(start.z);
                     if (same) {
                         start.x = ulp_step(start.x, d.x < 0);
                         start.y = ulp_step(start.y, d.y < 0);
                         start.z = ulp_step(start.z, d.z < 0);
-                        same = fx == (float)(int)start.x && fy == (float)(int)start.y && fz == (float)(int)start.z;
+                        same = fx == (float)f2i(start.x) && fy == (float)f2i(start.y) && fz == (float)f2i(start.z);
                         if (same) {
-                            const int ncx = chx + (nc_axis == 0 ? sgx : 0), ncy = chy + (nc_axis == 1 ? sgy : 0),
-                                      ncz = chz + (nc_axis == 2 ? sgz : 0);
+                            // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from
+                            // the clamped HitCell by one when the walk started on a far face (edge rule)
+                            const int axis = nc_axis & 3;
+                            const int ncx = chx + ((nc_axis >> 2) & 1) + (axis == 0 ? sgx : 0);
+                            const int ncy = chy + ((nc_axis >> 3) & 1) + (axis == 1 ? sgy : 0);
+                            const int ncz = chz + ((nc_axis >> 4) & 1) + (axis == 2 ? sgz : 0);
                             float gx = (float)ncx - start.x, gy = (float)ncy - start.y, gz = (float)ncz - start.z;
                             float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
                             if (mx < my && mx < mz)
@@ -281,9 +285,11 @@ struct WaveTracer {
         chz = box_hit ? qz : chz;
         c_code = box_hit ? bc : c_code;
         slot = box_hit ? meta.x : slot;
-        // the exit iteration's extra advance (:290-322) only matters through NextCell's axis
+        // the exit iteration's extra advance (:290-322) only matters through NextCell: keep its axis (bits 0-1)
+        // and, per axis, whether the unclamped cell sits one past the clamped HitCell (bits 2-4; edge rule only)
         const int axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
-        nc_axis = box_hit ? axis : nc_axis;
+        const int packed = axis | ((cell_x - qx) << 2) | ((cell_y - qy) << 3) | ((cell_z - qz) << 4);
+        nc_axis = box_hit ? packed : nc_axis;
     }
 
     // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane
@@ -363,7 +369,7 @@ struct WaveTracer {
 // one ray per lane, entered by the whole wave at a converged point
 template <bool STATS>
 __device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
-                           TraceResult& out, RayCounters& cnt)
+                           TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr)
 {
     WaveTracer<STATS> T;
     T.init(W);
@@ -391,6 +397,12 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
         }
         if (STATS)
             cnt.walk_lanes += (uint32_t)__popcll(__ballot(T.st == ST_WALK));
+        if (STATS && dbg && cnt.iters <= 400u) {  // development trace of one lane (the caller passes dbg for lane 0 only)
+            unsigned int* row = dbg + (cnt.iters - 1u) * 12u;
+            row[0] = T.st; row[1] = T.fine; row[2] = (unsigned)T.cell_x; row[3] = (unsigned)T.cell_y; row[4] = (unsigned)T.cell_z;
+            row[5] = __float_as_uint(T.tn_x); row[6] = __float_as_uint(T.tn_y); row[7] = __float_as_uint(T.tn_z);
+            row[8] = (unsigned)T.steps; row[9] = (unsigned)T.total; row[10] = __float_as_uint(T.ws.x); row[11] = __float_as_uint(T.ws.y);
+        }
         T.step(W);
     }
     T.result(W, out);
