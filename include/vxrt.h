@@ -136,8 +136,13 @@ typedef struct vxrt_render_flags {
     int32_t strip_rows, strip_count, strip_index;
     int32_t compact;         /* 1: d_fb (and AOVs) hold only this shard's strips, packed in order */
     int32_t collect_stats;   /* 1: also count probes (slower kernel variant); rays are always counted */
+    int32_t tile_schedule;   /* persistent kernel: 1 (default) = hand out the rows of 8x8 pixel tiles expected-longest
+                                first (ranked per frame on the host by the elevation of the row's centre ray in a
+                                Y-up world); 0 = row-major.  Scheduling only: results do not depend on it */
     float *d_color_aov;      /* optional W*H*3 float colour handed to the pixel store, or NULL */
     int64_t *d_hit_aov;      /* optional W*H primary hit voxel index (x + X*(y + Y*z)) or -1, or NULL */
+    const uint32_t *d_tile_order; /* optional caller-made hand-out order, overrides tile_schedule: a permutation of
+                                0 .. ceil(W/8)*ceil(rows/8)-1 (tile = tx + ty*ceil(W/8), rows = the launch grid's), or NULL */
     void *stream;
 } vxrt_render_flags;
 

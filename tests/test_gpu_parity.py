@@ -230,6 +230,45 @@ def test_strip_sharding_reassembles_the_frame(eng, vxo, count, rows):
     assert np.array_equal(full.cpu().numpy(), w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"])
 
 
+def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
+    """The persistent kernel hands out 8x8 tiles in an order (device-made horizon-first schedule by default, or the
+    caller's permutation).  Frames large enough for the queue to matter (> waves tiles) must come out identical
+    to the oracle whatever the order, also for a sharded launch grid."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    W, H = 1004, 516   # 126 x 65 tiles, ragged on both edges
+    ntiles = ((W + 7) // 8) * ((H + 7) // 8)
+    pos, f, u, r = helpers.camera("A", w.dims, vxo)
+    p = vxo.make_params(W, H, pos, f, u, r, frame_number=3, shadow=1, bounce_samples=1)
+    want = w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"]
+    base = dict(shadow=True, bounce_samples=1, frame_number=3)
+    rng = np.random.default_rng(5)
+    orders = {
+        "row-major": (dict(tile_schedule=False), None),
+        "device schedule": (dict(tile_schedule=True), None),
+        "host schedule": (dict(), torch.from_numpy(vx.tile_schedule(W, range(H), f, u, r, 90.0, H).astype(np.int32)).cuda()),
+        "random": (dict(), torch.from_numpy(rng.permutation(ntiles).astype(np.int32)).cuda()),
+    }
+    for name, (kw, order) in orders.items():
+        fb = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        ctx.RenderScreen(W, H, fb, pos, f, u, r, vx.RenderOptions(**base, **kw), tile_order=order)
+        st = ctx.frame_stats()
+        assert st.primary_rays == W * H, name
+        assert np.array_equal(fb.cpu().numpy(), want), name
+    # sharded launch grid (rows of the shard only) with the device schedule
+    count, rows = 2, 16
+    max_rows = max(vx.compact_rows(H, rows, count, i) for i in range(count))
+    stride = max_rows * W * 4
+    shards = torch.zeros((count, stride), dtype=torch.uint8, device="cuda")
+    for i in range(count):
+        ctx.RenderScreen(W, H, shards[i], pos, f, u, r,
+                         vx.RenderOptions(strip_rows=rows, strip_count=count, strip_index=i, compact=True, **base))
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+    ctx.deinterleave_strips(W, H, rows, count, shards, stride, out)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("gen,shape,factor", [(0, (128, 128, 128), 16), (2, (256, 256, 256), 32),
                                               (1, (128, 128, 128), 16), (2, (64, 64, 128), 8)])
 def test_device_world_builder_matches_oracle(eng, vxo, gen, shape, factor):

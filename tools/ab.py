@@ -24,7 +24,12 @@ cams = []
 for cname, frac, euler in bench.CAMERAS:
     f, u, r = vx.GetDirections(euler)
     cams.append((cname, (frac[0] * X, frac[1] * Y, frac[2] * Z), f, u, r))
-opts = vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, frame_number=1)
+opts = vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, frame_number=1,
+                        tile_schedule=not os.environ.get("AB_NOSCHED"))  # AB_SCHEDULE=1: host-made order instead
+sched = {}
+if os.environ.get('AB_SCHEDULE'):
+    for cname, pos, f, u, r in cams:
+        sched[cname] = torch.from_numpy(vx.tile_schedule(W, range(H), f, u, r, 90.0, H).astype(np.int32)).cuda()
 times = {(v, c[0]): [] for v in variants for c in cams}
 rays = {}
 ref = {}
@@ -34,7 +39,7 @@ for rnd in range(rounds + 1):
         for cname, pos, f, u, r in cams:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            ctx.RenderScreen(W, H, fb, pos, f, u, r, opts)
+            ctx.RenderScreen(W, H, fb, pos, f, u, r, opts, tile_order=sched.get(cname))
             b.record()
             torch.cuda.synchronize()
             if rnd == 0:

@@ -57,8 +57,8 @@ class RenderFlags(C.Structure):
         ("bounce_samples", C.c_int32), ("bounce_all_hits", C.c_int32), ("ortho", C.c_int32),
         ("frame_number", C.c_int64),
         ("strip_rows", C.c_int32), ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("compact", C.c_int32),
-        ("collect_stats", C.c_int32),
-        ("d_color_aov", C.c_void_p), ("d_hit_aov", C.c_void_p), ("stream", C.c_void_p),
+        ("collect_stats", C.c_int32), ("tile_schedule", C.c_int32),
+        ("d_color_aov", C.c_void_p), ("d_hit_aov", C.c_void_p), ("d_tile_order", C.c_void_p), ("stream", C.c_void_p),
     ]
 
 

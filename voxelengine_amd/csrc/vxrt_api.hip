@@ -4,12 +4,14 @@
 #include "../../include/vxrt.h"
 #include "vxrt_kernels.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace vxrt {
@@ -135,6 +137,41 @@ int adopt_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t nslots, uint3
 }
 
 int set_error(int code, const char* msg) { return fail(code, msg); }
+
+// Default hand-out order of the persistent kernel's tile queue: expected-longest ray chains first, so that what is
+// still in flight when the queue runs dry is cheap.  The cost proxy needs the camera only: the elevation of the
+// centre ray of each 8-pixel tile row in a Y-up world -- rays just below the horizon travel farthest, rays
+// pointing up leave the grid at once.  A few hundred flops on the host per frame; scheduling only.
+static void schedule_tile_rows(RenderArgs& A)
+{
+    const unsigned nty = (A.launch_rows + 7u) / 8u;
+    A.row_order_n = 0;
+    if (nty < 2 || nty > kMaxScheduledTileRows)
+        return;
+    std::vector<std::pair<float, uint16_t>> key(nty);
+    for (unsigned j = 0; j < nty; ++j) {
+        unsigned row = j * 8u + 4u < A.launch_rows ? j * 8u + 4u : A.launch_rows - 1u;
+        unsigned y = row;  // launch row -> frame row (pixel_coords in vxrt_persist.hpp)
+        if (A.checkerboard)
+            y = 2u * row;
+        else if (A.strip_count > 1)
+            y = ((row / (unsigned)A.strip_rows) * (unsigned)A.strip_count + (unsigned)A.strip_index) * (unsigned)A.strip_rows +
+                row % (unsigned)A.strip_rows;
+        const float sv = ((float)y / (float)A.height) * 2.0f - 1.0f;
+        float dy = A.fwd.y;
+        if (!A.ortho) {
+            const float dx = A.fwd.x + sv * A.ky * A.up.x, dz = A.fwd.z + sv * A.ky * A.up.z;
+            dy = A.fwd.y + sv * A.ky * A.up.y;
+            const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+            dy = len > 0.0f ? dy / len : dy;
+        }
+        key[j] = {dy < 0.0f ? -dy : 2.0f + dy, (uint16_t)j};  // grazing-down first ... straight down, then up
+    }
+    std::stable_sort(key.begin(), key.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (unsigned j = 0; j < nty; ++j)
+        A.row_order[j] = key[j].second;
+    A.row_order_n = nty;
+}
 
 }  // namespace vxrt
 
@@ -359,6 +396,7 @@ void vxrt_render_flags_default(vxrt_render_flags* f)
     f->frame_number = -1;
     f->strip_rows = 16;
     f->strip_count = 1;
+    f->tile_schedule = 1;
 }
 
 uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_count, int32_t strip_index)
@@ -447,6 +485,9 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
     A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
     A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount);
     A.persistent_waves = c->persistent_waves;
+    A.tile_order = fl->d_tile_order;
+    if (fl->tile_schedule && !A.tile_order && c->kernel_variant == 2)
+        schedule_tile_rows(A);
     vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
     VX_HIP(hipGetLastError());
     return VXRT_OK;

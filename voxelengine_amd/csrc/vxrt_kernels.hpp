@@ -21,6 +21,8 @@ enum StatSlot {
     kStatCount
 };
 
+constexpr unsigned kMaxScheduledTileRows = 512;  // frames up to 4096 launch rows get a tile schedule
+
 // Everything screenDispatch read from dFrameInfo / g_env / its arguments (Renderer.cu:7-24,89,179-181),
 // passed by value with the launch: no per-frame symbol copy.
 struct RenderArgs {
@@ -40,6 +42,11 @@ struct RenderArgs {
     unsigned long long* stats;
     unsigned int* tile_counter;  // persistent kernel: next 8x8 tile of the launch grid to hand out (zeroed per launch)
     unsigned int persistent_waves;
+    const unsigned int* tile_order;  // optional permutation of the launch grid's 8x8 tiles (hand-out order), or NULL
+    // default hand-out order, tile-row granular: the k-th tile row handed out is row_order[k] (row_order_n = number
+    // of tile rows, 0 = row-major).  Filled per frame by the host from the camera (vxrt_api.hip).
+    unsigned int row_order_n;
+    uint16_t row_order[kMaxScheduledTileRows];
 };
 
 struct BatchArgs {

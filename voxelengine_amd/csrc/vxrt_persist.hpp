@@ -101,6 +101,11 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
     const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
     uint32_t tile = 0, tile_used = 64u;
     bool drained = false;
+    unsigned long long dg_iters = 0, dg_walk = 0, dg_drain = 0;  // STATS only: loop diagnostics
+    const unsigned long long dg_t0 = STATS ? wall_clock64() : 0ull;
+#ifdef VXRT_TAIL_DEBUG
+    unsigned long long px_t0 = 0;
+#endif
 
     const f3 L = A.light_dir;
     const f3 sray = unit3(L);
@@ -144,6 +149,11 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end), n_next = __popcll(m_next);
+        if (STATS) {
+            dg_iters += 1;
+            dg_walk += (unsigned long long)n_walk;
+            dg_drain += drained ? 1ull : 0ull;
+        }
 
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
@@ -239,6 +249,14 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
                 }
                 if (finalize) {
                     store_pixel(pc, origin, ray, stage != PX_NONE, normal, position, color);
+#ifdef VXRT_TAIL_DEBUG  // development: when each pixel's chain started / ended (100 MHz ticks), and its primary steps
+                    if (STATS && A.color_aov) {
+                        float* o = A.color_aov + ((size_t)pc.out_row * A.width + (size_t)pc.x) * 3;
+                        o[0] = (float)(px_t0 & 0xFFFFFFull);
+                        o[1] = (float)(wall_clock64() & 0xFFFFFFull);
+                        o[2] = (float)p_steps;
+                    }
+#endif
                     stage = PX_NONE;
                 }
             }
@@ -255,6 +273,12 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
                         drained = true;
                         break;
                     }
+                    // hand-out order: expected-longest ray chains first, so that what is still in flight when the
+                    // queue runs dry is cheap (the host ranks the tile rows by the elevation of their centre ray)
+                    if (A.tile_order)
+                        tile = A.tile_order[tile];
+                    else if (A.row_order_n)
+                        tile = (uint32_t)A.row_order[tile / ntx] * ntx + tile % ntx;
                     tile_used = 0u;
                 }
                 const uint32_t avail = 64u - tile_used;
@@ -277,6 +301,9 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
                 n_primary += 1;
                 launch = true;
                 stage = PX_PRIMARY;
+#ifdef VXRT_TAIL_DEBUG
+                px_t0 = wall_clock64();
+#endif
             }
             if (launch)
                 T.begin_ray(W, l_origin, l_dir, l_max);
@@ -308,6 +335,10 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
             atomicAdd(&A.stats[kStatCoarseProbes], p0);
             atomicAdd(&A.stats[kStatBrickEntries], p1);
             atomicAdd(&A.stats[kStatFineProbes], p2);
+            atomicAdd(&A.stats[kStatDbgIters], dg_iters);
+            atomicAdd(&A.stats[kStatDbgWalkLanes], dg_walk);
+            atomicAdd(&A.stats[kStatDbgEndRuns], wall_clock64() - dg_t0);  // wave lifetime, 100 MHz ticks
+            atomicAdd(&A.stats[kStatDbgBoxRuns], dg_drain);                // iterations after the queue ran dry
         }
     }
 }

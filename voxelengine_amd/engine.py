@@ -28,6 +28,27 @@ def GetDirections(euler):
     return (np.array(f[:], np.float32), np.array(u[:], np.float32), np.array(r[:], np.float32))
 
 
+def tile_schedule(width: int, frame_rows, fwd, up, right, fov_deg: float = 90.0, height: int | None = None):
+    """Hand-out order of the 8x8 pixel tiles for the persistent render kernel: expected-longest ray chains first,
+    so the wave-level tail at the end of a frame is made of cheap tiles.  A function of the camera only: the cost
+    proxy is the elevation of the tile's centre ray (rays pointing up leave the grid at once; rays just below the
+    horizon travel farthest).  ``frame_rows``: frame row of every launch-grid row (``range(height)`` for an
+    unsharded frame).  Returns uint32 numpy array; scheduling only -- results never depend on it."""
+    frame_rows = np.asarray(list(frame_rows), np.int64)
+    H = int(height if height is not None else (frame_rows.max() + 1 if frame_rows.size else 1))
+    ntx, nty = (width + 7) // 8, (len(frame_rows) + 7) // 8
+    t = np.tan(np.float64(fov_deg) * 3.1415 / 180.0 / 2.0)
+    cx = (np.arange(ntx) * 8 + 4) / width * 2 - 1
+    rows_c = frame_rows[np.minimum(np.arange(nty) * 8 + 4, len(frame_rows) - 1)] if len(frame_rows) else np.zeros(0)
+    cy = rows_c / H * 2 - 1
+    f, u, r = [np.asarray(v, np.float64) for v in (fwd, up, right)]
+    d = f[None, None, :] + (cx[None, :, None] * t * (width / H)) * r[None, None, :] + (cy[:, None, None] * t) * u[None, None, :]
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    dy = d[..., 1]
+    cost = np.where(dy >= 0, 0.0, 1.0 / np.maximum(-dy, 0.02))  # up-pointing: cheap; grazing: expensive (capped)
+    return np.argsort(-cost.reshape(-1), kind="stable").astype(np.uint32)
+
+
 def compact_rows(height: int, strip_rows: int, strip_count: int, strip_index: int) -> int:
     return int(N.load().vxrt_compact_rows(height, strip_rows, strip_count, strip_index))
 
@@ -47,6 +68,7 @@ class RenderOptions:
     strip_index: int = 0
     compact: bool = False
     collect_stats: bool = False
+    tile_schedule: bool = True      # persistent kernel: expected-longest tiles first (scheduling only)
     extra: dict = field(default_factory=dict)
 
 
@@ -124,7 +146,7 @@ class Context:
 
     # ---- per frame -------------------------------------------------------------------------------
     def RenderScreen(self, width: int, height: int, d_fb, origin, fwd, up, right, opts: RenderOptions | None = None,
-                     color_aov=None, hit_aov=None, stream: int | None = None) -> None:
+                     color_aov=None, hit_aov=None, stream: int | None = None, tile_order=None) -> None:
         """Graphics::RenderScreen (VoxelRT/Renderer.cu:305-328).  ``d_fb``/AOVs: torch CUDA tensors or raw
         device addresses.  Asynchronous on ``stream`` (default: torch's current stream)."""
         o = opts or RenderOptions()
@@ -135,8 +157,10 @@ class Context:
         fl.frame_number = int(o.frame_number)
         fl.strip_rows, fl.strip_count, fl.strip_index = int(o.strip_rows), int(o.strip_count), int(o.strip_index)
         fl.compact, fl.collect_stats = int(o.compact), int(o.collect_stats)
+        fl.tile_schedule = int(o.tile_schedule)
         fl.d_color_aov = _ptr(color_aov)
         fl.d_hit_aov = _ptr(hit_aov)
+        fl.d_tile_order = _ptr(tile_order)
         fl.stream = _stream(stream)
         N.check(self._L.vxrt_render(self._h, width, height, _ptr(d_fb), _f3(origin), _f3(fwd), _f3(up), _f3(right),
                                     C.byref(fl)))
