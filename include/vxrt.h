@@ -117,8 +117,10 @@ typedef struct vxrt_frame_stats {
     uint64_t coarse_probes; /* Nc: in-range coarse cell probes */
     uint64_t brick_entries; /* Nb */
     uint64_t fine_probes;   /* Nf: in-range brick cell probes */
-    uint64_t dbg[4];        /* wave-loop diagnostics (collect_stats launches): iterations, walking lanes summed
-                               over iterations, end-phase runs, box-phase runs */
+    uint64_t dbg[12];       /* wave-loop diagnostics of collect_stats launches, summed over waves: [0] iterations,
+                               [1] walking lanes over those iterations, [2] end-of-walk / [3] tight-box / [4] ray-finished
+                               phase executions, [5..7] lanes those executions served (same order); persistent kernel
+                               only: [8] wave lifetime in 100 MHz ticks, [9] iterations after the tile queue ran dry */
 } vxrt_frame_stats;
 
 typedef struct vxrt_render_flags {

@@ -19,6 +19,8 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+#define VXRT_HOST_CHECK 1
+static inline uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }  // v_mad_u32_u24
 static inline int __float2int_rz(float v) { if (!(v == v)) return 0; if (v >= 2147483648.0f) return 2147483647; if (v <= -2147483648.0f) return (-2147483647 - 1); return (int)v; }
 using std::min;
 using std::max;

@@ -25,7 +25,7 @@ for shadow, bounce in ((0, 0), (1, 0), (1, 1)):
         ctx.RenderScreen(W, H, fb, pos, f, u, r, vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, frame_number=1,
                                                                collect_stats=True))
         st = ctx.frame_stats()
-        iters, walk, endr, boxr = [int(v) for v in st.dbg]
+        iters, walk, endr, boxr = [int(v) for v in st.dbg][:4]
         probes = st.coarse_probes + st.fine_probes
         print("shadow=%d bounce=%d cam %s: rays %.2fM probes/ray %.1f | iters/wave %.0f  walking lanes/iter %.1f  useful probes/iter %.1f "
               "(%.0f%%)  end runs/wave %.1f box runs/wave %.1f | END events/ray %.2f BOX events/ray %.2f" % (

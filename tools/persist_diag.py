@@ -40,9 +40,12 @@ for cname, frac, euler in bench.CAMERAS:
     torch.cuda.synchronize()
     ms = a.elapsed_time(b)
     st = ctx.frame_stats()
-    iters, walk, life, drain = [int(v) for v in st.dbg]
+    iters, walk, end_r, box_r, next_r, end_l, box_l, next_l, life, drain = [int(v) for v in st.dbg][:10]
     probes = st.coarse_probes + st.fine_probes
     print("%s cam %s sched=%d: %.3f ms (counting kernel) rays %.2fM | iters/wave %.0f  walking lanes/iter %.1f  probes/iter %.1f | "
           "mean wave lifetime %.3f ms = %.0f%% of launch | drained iterations %.1f%%" % (
               name, cname, int(use_sched), ms, st.total_rays() / 1e6, iters / nwaves, walk / max(iters, 1), probes / max(iters, 1),
               life / nwaves / 1e5, 100.0 * life / nwaves / 1e5 / ms, 100.0 * drain / max(iters, 1)), flush=True)
+    print("    phase executions per 100 iterations (lanes served per execution): next %.1f (%.1f)  end %.1f (%.1f)  box %.1f (%.1f)" % (
+        100.0 * next_r / max(iters, 1), next_l / max(next_r, 1), 100.0 * end_r / max(iters, 1), end_l / max(end_r, 1),
+        100.0 * box_r / max(iters, 1), box_l / max(box_r, 1)), flush=True)

@@ -37,7 +37,7 @@ class WorldInfo(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("bounce_rays", C.c_uint64),
                 ("primary_hits", C.c_uint64), ("coarse_probes", C.c_uint64), ("brick_entries", C.c_uint64),
-                ("fine_probes", C.c_uint64), ("dbg", C.c_uint64 * 4)]
+                ("fine_probes", C.c_uint64), ("dbg", C.c_uint64 * 12)]
 
     def total_rays(self) -> int:
         return int(self.primary_rays + self.shadow_rays + self.bounce_rays)

@@ -203,6 +203,9 @@ int vxrt_create(int device, vxrt_ctx** out)
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
         c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
+        if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments only
+            if (atoi(e) > 0 && atoi(e) <= 32)
+                c->persistent_waves = (unsigned)prop.multiProcessorCount * (unsigned)atoi(e);
     }
     if (e != hipSuccess) {
         delete c;
@@ -513,6 +516,13 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     out->dbg[1] = h[vxrt::kStatDbgWalkLanes];
     out->dbg[2] = h[vxrt::kStatDbgEndRuns];
     out->dbg[3] = h[vxrt::kStatDbgBoxRuns];
+    out->dbg[4] = h[vxrt::kStatDbgNextRuns];
+    out->dbg[5] = h[vxrt::kStatDbgEndLanes];
+    out->dbg[6] = h[vxrt::kStatDbgBoxLanes];
+    out->dbg[7] = h[vxrt::kStatDbgNextLanes];
+    out->dbg[8] = h[vxrt::kStatDbgLifetime];
+    out->dbg[9] = h[vxrt::kStatDbgDrained];
+    out->dbg[10] = out->dbg[11] = 0;
     return VXRT_OK;
 }
 

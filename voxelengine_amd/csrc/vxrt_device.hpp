@@ -65,11 +65,21 @@ struct RayCounters {
 __device__ __forceinline__ int f2i(float v) { return __float2int_rz(v); }
 
 // 8x8x8 tiled-linear bit address (GetSampleIndex, VolumeRaytracer.cuh:107-131)
+#ifndef VXRT_HOST_CHECK  // tools/host_wave_check.cpp runs this header on the host and brings its own mad24
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+#endif
+
 __device__ __forceinline__ uint32_t tiled_index(int x, int y, int z, int tw, int twh)
 {
-    // 24-bit multiplies (full rate; v_mul_lo_u32 is quarter rate): tiles per axis < 2^13, tiles per slice < 2^24
-    // (checked when a world is uploaded or built)
-    uint32_t tile = (uint32_t)(x >> 3) + __umul24((uint32_t)(y >> 3), (uint32_t)tw) + __umul24((uint32_t)(z >> 3), (uint32_t)twh);
+    // 24-bit multiply-adds (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate): tiles per axis < 2^13,
+    // tiles per slice < 2^24 (checked when a world is uploaded or built).  Spelled as the instruction: given
+    // __umul24 the compiler still selects the 32-bit multiply when it cannot prove the operands' width.
+    const uint32_t tile = mad24((uint32_t)(z >> 3), (uint32_t)twh, mad24((uint32_t)(y >> 3), (uint32_t)tw, (uint32_t)(x >> 3)));
     return tile * 512u + (uint32_t)((x & 7) | ((y & 7) << 3) | ((z & 7) << 6));
 }
 

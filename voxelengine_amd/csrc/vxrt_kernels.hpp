@@ -16,8 +16,14 @@ enum StatSlot {
     kStatFineProbes,
     kStatDbgIters,      // wave-loop iterations, summed over waves (diagnostics)
     kStatDbgWalkLanes,  // walking lanes summed over those iterations
-    kStatDbgEndRuns,
+    kStatDbgEndRuns,    // executions of the end-of-walk phase, and (EndLanes) the lanes they served
     kStatDbgBoxRuns,
+    kStatDbgNextRuns,   // persistent kernel: executions of the ray-finished phase
+    kStatDbgEndLanes,
+    kStatDbgBoxLanes,
+    kStatDbgNextLanes,
+    kStatDbgLifetime,   // persistent kernel: wave lifetime, 100 MHz ticks summed over waves
+    kStatDbgDrained,    // persistent kernel: iterations after the tile queue ran dry
     kStatCount
 };
 

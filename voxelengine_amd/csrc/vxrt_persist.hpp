@@ -79,8 +79,11 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, int x, int y, f3
     }
 }
 
+#ifndef VXRT_PERSIST_OCC
+#define VXRT_PERSIST_OCC 4  // waves per SIMD the register budget is sized for (128 VGPRs)
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
+__global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderArgs A)
 {
     const WorldView& W = A.W;
     const int lane = threadIdx.x & 63;
@@ -99,9 +102,13 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
 
     // the wave's share of the tile queue (wave-uniform)
     const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
+    // Whole tiles per ticket: one same-address atomic per 64 pixels.  A finer queue is limited by the atomic rate
+    // (measured: 2x slower frames at 8 pixels per ticket), and handing out only the last tiles in smaller pieces
+    // did not shorten the frame either.
     uint32_t tile = 0, tile_used = 64u;
     bool drained = false;
     unsigned long long dg_iters = 0, dg_walk = 0, dg_drain = 0;  // STATS only: loop diagnostics
+    unsigned int dg_runs[3] = {0, 0, 0}, dg_lanes[3] = {0, 0, 0};  // next / end / box phase executions, lanes served
     const unsigned long long dg_t0 = STATS ? wall_clock64() : 0ull;
 #ifdef VXRT_TAIL_DEBUG
     unsigned long long px_t0 = 0;
@@ -153,6 +160,14 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
             dg_iters += 1;
             dg_walk += (unsigned long long)n_walk;
             dg_drain += drained ? 1ull : 0ull;
+            const bool r_next = vote_run(n_next, n_walk + n_box + n_end), r_end = vote_run(n_end, n_walk + n_box),
+                       r_box = vote_run(n_box, n_walk);
+            dg_runs[0] += r_next ? 1u : 0u;
+            dg_runs[1] += r_end ? 1u : 0u;
+            dg_runs[2] += r_box ? 1u : 0u;
+            dg_lanes[0] += r_next ? (unsigned)n_next : 0u;
+            dg_lanes[1] += r_end ? (unsigned)n_end : 0u;
+            dg_lanes[2] += r_box ? (unsigned)n_box : 0u;
         }
 
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
@@ -273,13 +288,13 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
                         drained = true;
                         break;
                     }
+                    tile_used = 0u;
                     // hand-out order: expected-longest ray chains first, so that what is still in flight when the
                     // queue runs dry is cheap (the host ranks the tile rows by the elevation of their centre ray)
                     if (A.tile_order)
                         tile = A.tile_order[tile];
                     else if (A.row_order_n)
                         tile = (uint32_t)A.row_order[tile / ntx] * ntx + tile % ntx;
-                    tile_used = 0u;
                 }
                 const uint32_t avail = 64u - tile_used;
                 const bool wants = ((want >> lane) & 1ull) != 0ull;
@@ -337,8 +352,14 @@ __global__ __launch_bounds__(64, 4) void k_render_persist(RenderArgs A)
             atomicAdd(&A.stats[kStatFineProbes], p2);
             atomicAdd(&A.stats[kStatDbgIters], dg_iters);
             atomicAdd(&A.stats[kStatDbgWalkLanes], dg_walk);
-            atomicAdd(&A.stats[kStatDbgEndRuns], wall_clock64() - dg_t0);  // wave lifetime, 100 MHz ticks
-            atomicAdd(&A.stats[kStatDbgBoxRuns], dg_drain);                // iterations after the queue ran dry
+            atomicAdd(&A.stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);
+            atomicAdd(&A.stats[kStatDbgEndRuns], (unsigned long long)dg_runs[1]);
+            atomicAdd(&A.stats[kStatDbgBoxRuns], (unsigned long long)dg_runs[2]);
+            atomicAdd(&A.stats[kStatDbgNextLanes], (unsigned long long)dg_lanes[0]);
+            atomicAdd(&A.stats[kStatDbgEndLanes], (unsigned long long)dg_lanes[1]);
+            atomicAdd(&A.stats[kStatDbgBoxLanes], (unsigned long long)dg_lanes[2]);
+            atomicAdd(&A.stats[kStatDbgLifetime], wall_clock64() - dg_t0);
+            atomicAdd(&A.stats[kStatDbgDrained], dg_drain);
         }
     }
 }
