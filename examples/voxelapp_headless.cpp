@@ -4,6 +4,11 @@
 // is a scripted path instead of keyboard/mouse input; the last frame is written as raw BGRA and as a PPM.
 //
 //   voxelapp_headless [world_edge=256] [frames=2] [out_prefix=frame] [width=320] [height=180] [shaded=0]
+//                     [camera_path_file] [dump_every_frame=0]
+//
+// camera_path_file replaces the fixed camera: one frame per line, "x y z eulerX eulerY eulerZ" (voxels, radians;
+// '#' starts a comment); `frames` is then the number of lines.  With dump_every_frame=1 each frame is also written
+// as <out_prefix>_NNNN.ppm (under checkerboard rendering a frame keeps the other half of the previous one).
 #include "../include/GPUDDA/Renderer.h"
 #include "../include/GPUDDA/VoxelWorldBuilder.h"
 
@@ -28,6 +33,33 @@ int main(int argc, char** argv)
     const std::string prefix = argc > 3 ? argv[3] : "frame";
     const uint32_t width = argc > 4 ? (uint32_t)atoi(argv[4]) : 320u, height = argc > 5 ? (uint32_t)atoi(argv[5]) : 180u;
     const bool shaded = argc > 6 && atoi(argv[6]) != 0;
+    const std::string path_file = argc > 7 ? argv[7] : "";
+    const bool dump_all = argc > 8 && atoi(argv[8]) != 0;
+
+    struct Pose {
+        float3 pos, euler;
+    };
+    std::vector<Pose> path;
+    if (!path_file.empty()) {
+        std::ifstream in(path_file);
+        if (!in) {
+            std::cerr << "cannot open camera path " << path_file << std::endl;
+            return 2;
+        }
+        std::string line;
+        while (std::getline(in, line)) {
+            const size_t hash = line.find('#');
+            if (hash != std::string::npos)
+                line.resize(hash);
+            float v[6];
+            if (std::sscanf(line.c_str(), "%f %f %f %f %f %f", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5]) == 6)
+                path.push_back({make_float3(v[0], v[1], v[2]), make_float3(v[3], v[4], v[5])});
+        }
+        if (path.empty()) {
+            std::cerr << "camera path " << path_file << " holds no poses" << std::endl;
+            return 2;
+        }
+    }
 
     int factor = 32;
     auto t0 = std::chrono::high_resolution_clock::now();
@@ -76,8 +108,22 @@ int main(int argc, char** argv)
     (void)hipMemset(d_pixels, 255, (size_t)width * height * sizeof(BGRA8888));
     std::vector<BGRA8888> pixels((size_t)width * height);
 
+    auto write_ppm = [&](const std::string& name) {
+        std::ofstream ppm(name, std::ios::binary);
+        ppm << "P6\n" << width << " " << height << "\n255\n";
+        for (const auto& p : pixels) {
+            const char rgb[3] = {(char)p.r, (char)p.g, (char)p.b};
+            ppm.write(rgb, 3);
+        }
+    };
+
     double avgFrameTime = 0.0;
-    for (int i = 0; i < frames; ++i) {
+    const int nframes = path.empty() ? frames : (int)path.size();
+    for (int i = 0; i < nframes; ++i) {
+        if (!path.empty()) {
+            cam_pos = path[(size_t)i].pos;
+            cam_eular = path[(size_t)i].euler;
+        }
         auto f0 = std::chrono::high_resolution_clock::now();
         GetDirections(cam_eular, &cam_forward, &cam_up, &cam_right);
         RenderScreen(raytracer, width, height, d_pixels, cam_pos, cam_forward, cam_up, cam_right);
@@ -85,17 +131,17 @@ int main(int argc, char** argv)
         auto f1 = std::chrono::high_resolution_clock::now();
         double td = std::chrono::duration_cast<std::chrono::microseconds>(f1 - f0).count() / 1000.0;
         avgFrameTime = i == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
+        if (dump_all) {
+            char name[32];
+            std::snprintf(name, sizeof(name), "_%04d.ppm", i);
+            write_ppm(prefix + name);
+        }
     }
     std::cout << "Avg FPS: " << 1000.0 / avgFrameTime << std::endl;
 
     std::ofstream raw(prefix + ".bgra", std::ios::binary);
     raw.write(reinterpret_cast<const char*>(pixels.data()), (std::streamsize)(pixels.size() * sizeof(BGRA8888)));
-    std::ofstream ppm(prefix + ".ppm", std::ios::binary);
-    ppm << "P6\n" << width << " " << height << "\n255\n";
-    for (const auto& p : pixels) {
-        const char rgb[3] = {(char)p.r, (char)p.g, (char)p.b};
-        ppm.write(rgb, 3);
-    }
+    write_ppm(prefix + ".ppm");
     // a few batch queries through VoxelRaytracer3D::Raytrace
     std::vector<float3> o(4, cam_pos), d = {make_float3(0, -1, 0), make_float3(1, -1, 0), make_float3(0, 1, 0), cam_forward};
     auto res = raytracer->Raytrace(o, d);

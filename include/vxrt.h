@@ -99,6 +99,19 @@ int vxrt_world_info_get(vxrt_ctx *ctx, vxrt_world_info *out);
 int vxrt_download_world(vxrt_ctx *ctx, uint32_t *coarse_bits, uint32_t *brick_slot, float *bounds,
                         uint32_t *pool);
 
+/* ---- brickmap file.  The reference rebuilds its world at every start (VoxelApp/main.cu:41-49:
+ * CreateVoxels + GenerateLowresVoxelBuffer, minutes at 8k scale on its host threads); a built brickmap can be
+ * kept instead.  Layout (little endian): 104-byte header {"VXBRKMAP", u32 version = 1, u32 header bytes,
+ * i32 factor, i32 cdims[3], u64 ncells, u64 nslots, u64 bytes of the three streams, u64 word sums of the three
+ * streams, u64 reserved}, then the streams as they lie in HBM: coarse_bits (as in vxrt_world_desc), one 8-byte
+ * record per cell {u32 pool slot or VXRT_EMPTY_SLOT, u32 extents: min x,y,z then max x,y,z, 5 bits each from bit 0}
+ * in the order of coarse_bits, and the pool.  Loading validates sizes, sums and the cell table against the coarse
+ * bits, and streams through a 64 MiB staging buffer. */
+int vxrt_save_world(vxrt_ctx *ctx, const char *path);
+int vxrt_load_world(vxrt_ctx *ctx, const char *path);
+/* header of a brickmap file (no GPU needed); hbm_bytes = bytes the three streams will occupy */
+int vxrt_world_file_info(const char *path, vxrt_world_info *out);
+
 /* ---- camera / lighting state.  Replaces Graphics::SetEnvironment, ::SetFOV,
  * ::SetOrthoWindowSize, ::GetDirections (VoxelRT/Renderer.cu:27-42,278-303). */
 int vxrt_set_environment(vxrt_ctx *ctx, const float light_dir[3], const float light_color[3],

@@ -38,3 +38,36 @@ def test_headless_voxelapp_matches_oracle(vxo, tmp_path, shaded):
     # the batch rays the example prints: straight down from the camera hits, straight up misses
     lines = [l for l in out.stdout.splitlines() if l.startswith("ray ")]
     assert len(lines) == 4 and "valid=1" in lines[0] and "valid=0" in lines[2]
+
+
+@pytest.mark.gpu
+def test_headless_voxelapp_replays_a_camera_path(vxo, tmp_path):
+    """A fly-through read from a file (one pose per frame): GetDirections per frame, checkerboard frames that keep
+    half of their predecessor, every frame dumped as PPM; each dump equals the oracle's frame sequence."""
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    W, H, edge = 160, 96, 256
+    poses = [((64.0, 230.0, 64.0), (-0.45, 0.7, 0.0)), ((70.5, 228.0, 66.0), (-0.5, 0.8, 0.0)),
+             ((80.0, 220.25, 72.0), (-0.6, 1.0, 0.0))]
+    path = tmp_path / "path.txt"
+    path.write_text("# x y z eulerX eulerY eulerZ\n" + "".join(
+        "%r %r %r %r %r %r\n" % (*p, *e) for p, e in poses) + "\n# end\n")
+    prefix = str(tmp_path / "fly")
+    out = subprocess.run([EXE, str(edge), "0", prefix, str(W), str(H), "1", str(path), "1"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    w = vxo.World.generate(vxo.GEN_PERLIN_REF, edge, edge, edge, 32, nthreads=16)
+    fb = np.full((H, W, 4), 255, np.uint8)
+    for frame, (pos, euler) in enumerate(poses):
+        f, u, r = vxo.get_directions(euler)
+        p = vxo.make_params(W, H, tuple(np.float32(v) for v in pos), f, u, r, frame_number=frame, mode=vxo.MODE_SHADED,
+                            checkerboard=1, shadow=1, bounce_samples=1)
+        fb = w.render(p, fb=fb)["fb"]
+        raw = open("%s_%04d.ppm" % (prefix, frame), "rb").read()
+        head = b"P6\n%d %d\n255\n" % (W, H)
+        assert raw.startswith(head)
+        rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+        assert np.array_equal(rgb, fb[:, :, [2, 1, 0]]), frame   # memory order is b,g,r,a
+    assert np.array_equal(np.fromfile(prefix + ".bgra", np.uint8).reshape(H, W, 4), fb)
+    bad = subprocess.run([EXE, str(edge), "0", prefix, str(W), str(H), "1", str(tmp_path / "none.txt")],
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode == 2

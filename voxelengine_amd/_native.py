@@ -16,6 +16,7 @@ MODE_SHADED, MODE_DEBUG = 0, 1
 EXPORTS = [
     "vxrt_abi_version", "vxrt_create", "vxrt_destroy", "vxrt_last_error", "vxrt_synchronize", "vxrt_set_kernel_variant",
     "vxrt_upload_world", "vxrt_build_world_procedural", "vxrt_world_info_get", "vxrt_download_world",
+    "vxrt_save_world", "vxrt_load_world", "vxrt_world_file_info",
     "vxrt_set_environment", "vxrt_set_fov", "vxrt_set_ortho_window_size", "vxrt_get_directions",
     "vxrt_render_flags_default", "vxrt_render", "vxrt_compact_rows", "vxrt_frame_stats_get",
     "vxrt_deinterleave_strips", "vxrt_trace_batch", "vxrt_trace_batch_host",
@@ -97,6 +98,9 @@ def load() -> C.CDLL:
     L.vxrt_build_world_procedural.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.vxrt_world_info_get.argtypes = [C.c_void_p, C.POINTER(WorldInfo)]
     L.vxrt_download_world.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.vxrt_save_world.argtypes = [C.c_void_p, C.c_char_p]
+    L.vxrt_load_world.argtypes = [C.c_void_p, C.c_char_p]
+    L.vxrt_world_file_info.argtypes = [C.c_char_p, C.POINTER(WorldInfo)]
     L.vxrt_set_environment.argtypes = [C.c_void_p, f3, f3, f3]
     L.vxrt_set_fov.argtypes = [C.c_void_p, C.c_float]
     L.vxrt_set_ortho_window_size.argtypes = [C.c_void_p, C.c_float, C.c_float]

@@ -644,4 +644,178 @@ int vxrt_trace_batch_host(vxrt_ctx* c, const float* origins, const float* dirs, 
     return rc;
 }
 
+// ---- brickmap file: the resident tables as they lie in HBM, behind a versioned header ------
+namespace {
+
+constexpr char kFileMagic[8] = {'V', 'X', 'B', 'R', 'K', 'M', 'A', 'P'};
+constexpr uint32_t kFileVersion = 1;
+constexpr size_t kFileChunk = 64u << 20;  // staging buffer for the table streams
+
+struct FileHeader {  // 104 bytes, little endian
+    char magic[8];
+    uint32_t version, header_bytes;
+    int32_t factor, cdims[3];
+    uint64_t ncells, nslots;
+    uint64_t coarse_bytes, meta_bytes, pool_bytes;  // the three table streams, in this order after the header
+    uint64_t sum[3];                                 // per stream: sum of its 32-bit words, mod 2^64
+    uint64_t reserved;
+};
+static_assert(sizeof(FileHeader) == 104, "file header layout");
+
+uint64_t word_sum(const void* p, size_t bytes)
+{
+    const uint32_t* w = static_cast<const uint32_t*>(p);
+    uint64_t s = 0;
+    for (size_t i = 0; i < bytes / 4; ++i)
+        s += w[i];
+    return s;
+}
+
+struct FileCloser {
+    FILE* f;
+    ~FileCloser() { if (f) fclose(f); }
+};
+
+int read_header(FILE* f, const char* path, FileHeader& h)
+{
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kFileMagic, 8) != 0)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": not a brickmap file");
+    if (h.version != kFileVersion || h.header_bytes != sizeof(FileHeader))
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": unsupported brickmap file version");
+    int cd[3] = {h.cdims[0], h.cdims[1], h.cdims[2]};
+    int rc = vxrt::check_shape(h.factor, cd);
+    if (rc)
+        return rc;
+    const uint64_t ncells = (uint64_t)cd[0] * cd[1] * cd[2], bw = (uint64_t)h.factor * h.factor * h.factor / 32;
+    if (h.ncells != ncells || h.nslots > ncells || h.coarse_bytes != ((ncells + 31) / 32) * 4 ||
+        h.meta_bytes != ncells * sizeof(uint2) || h.pool_bytes != h.nslots * bw * 4)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": header sizes are inconsistent");
+    return VXRT_OK;
+}
+
+}  // namespace
+
+int vxrt_world_file_info(const char* path, vxrt_world_info* out)
+{
+    if (!path || !out)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": cannot open");
+    FileHeader h;
+    int rc = read_header(fc.f, path, h);
+    if (rc)
+        return rc;
+    out->factor = h.factor;
+    for (int a = 0; a < 3; ++a)
+        out->cdims[a] = h.cdims[a];
+    out->ncells = h.ncells;
+    out->nslots = h.nslots;
+    out->hbm_bytes = h.coarse_bytes + h.meta_bytes + h.pool_bytes;
+    return VXRT_OK;
+}
+
+int vxrt_save_world(vxrt_ctx* c, const char* path)
+{
+    if (!c || !path)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (!c->has_world)
+        return fail(VXRT_ERR_NO_WORLD, "no world resident");
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());
+    FileHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, kFileMagic, 8);
+    h.version = kFileVersion;
+    h.header_bytes = sizeof(FileHeader);
+    h.factor = c->view.f;
+    h.cdims[0] = c->view.cx;
+    h.cdims[1] = c->view.cy;
+    h.cdims[2] = c->view.cz;
+    h.ncells = c->ncells;
+    h.nslots = c->nslots;
+    h.coarse_bytes = ((c->ncells + 31) / 32) * 4;
+    h.meta_bytes = c->ncells * sizeof(uint2);
+    h.pool_bytes = c->nslots * (uint64_t)c->view.brick_words * 4;
+    FileCloser fc{fopen(path, "wb")};
+    if (!fc.f)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": cannot create");
+    if (fwrite(&h, sizeof(h), 1, fc.f) != 1)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed");
+    std::vector<unsigned char> stage(kFileChunk);
+    const void* src[3] = {c->d_coarse, c->d_meta, c->d_pool};
+    const uint64_t bytes[3] = {h.coarse_bytes, h.meta_bytes, h.pool_bytes};
+    for (int t = 0; t < 3; ++t)
+        for (uint64_t off = 0; off < bytes[t]; off += kFileChunk) {
+            const size_t n = (size_t)std::min<uint64_t>(kFileChunk, bytes[t] - off);
+            VX_HIP(hipMemcpy(stage.data(), static_cast<const unsigned char*>(src[t]) + off, n, hipMemcpyDeviceToHost));
+            h.sum[t] += word_sum(stage.data(), n);
+            if (fwrite(stage.data(), 1, n, fc.f) != n)
+                return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed (disk full?)");
+        }
+    if (fseek(fc.f, 0, SEEK_SET) != 0 || fwrite(&h, sizeof(h), 1, fc.f) != 1 || fflush(fc.f) != 0)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed");
+    return VXRT_OK;
+}
+
+int vxrt_load_world(vxrt_ctx* c, const char* path)
+{
+    if (!c || !path)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": cannot open");
+    FileHeader h;
+    int rc = read_header(fc.f, path, h);
+    if (rc)
+        return rc;
+    VX_HIP(hipSetDevice(c->device));
+    int cd[3] = {h.cdims[0], h.cdims[1], h.cdims[2]};
+    rc = vxrt::alloc_world(c, h.factor, cd, h.nslots);
+    if (rc)
+        return rc;
+    // stream the tables into HBM, checking on the way what vxrt_upload_world checks: every occupied coarse cell
+    // owns a brick inside the pool, every empty one owns none
+    std::vector<unsigned char> stage(kFileChunk);
+    std::vector<uint32_t> coarse(h.coarse_bytes / 4);
+    void* dst[3] = {c->d_coarse, c->d_meta, c->d_pool};
+    const uint64_t bytes[3] = {h.coarse_bytes, h.meta_bytes, h.pool_bytes};
+    auto bad = [&](const std::string& why) {
+        vxrt::free_world(c);
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": " + why);
+    };
+    for (int t = 0; t < 3; ++t) {
+        uint64_t sum = 0;
+        for (uint64_t off = 0; off < bytes[t]; off += kFileChunk) {
+            const size_t n = (size_t)std::min<uint64_t>(kFileChunk, bytes[t] - off);
+            if (fread(stage.data(), 1, n, fc.f) != n)
+                return bad("file is truncated");
+            sum += word_sum(stage.data(), n);
+            if (t == 0)
+                memcpy(reinterpret_cast<unsigned char*>(coarse.data()) + off, stage.data(), n);
+            if (t == 1) {
+                const uint2* m = reinterpret_cast<const uint2*>(stage.data());
+                const uint64_t first = off / sizeof(uint2);
+                for (size_t i = 0; i < n / sizeof(uint2); ++i) {
+                    const uint64_t cell = first + i;
+                    const bool bit = (coarse[cell >> 5] >> (cell & 31)) & 1u;
+                    if (bit ? m[i].x >= h.nslots : m[i].x != VXRT_EMPTY_SLOT)
+                        return bad("cell table does not match the coarse bits / pool size");
+                }
+            }
+            hipError_t e = hipMemcpy(static_cast<unsigned char*>(dst[t]) + off, stage.data(), n, hipMemcpyHostToDevice);
+            if (e != hipSuccess) {
+                vxrt::free_world(c);
+                return fail(VXRT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+            }
+        }
+        if (sum != h.sum[t])
+            return bad("checksum mismatch (corrupt file)");
+    }
+    c->nslots = h.nslots;
+    vxrt::fill_view(c, h.factor, cd);
+    c->has_world = true;
+    return VXRT_OK;
+}
+
 }  // extern "C"

@@ -10,6 +10,7 @@ the HIP kernels in ``csrc/``.  There is no CPU fallback: without libvxrt.so and 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
@@ -47,6 +48,13 @@ def tile_schedule(width: int, frame_rows, fwd, up, right, fov_deg: float = 90.0,
     dy = d[..., 1]
     cost = np.where(dy >= 0, 0.0, 1.0 / np.maximum(-dy, 0.02))  # up-pointing: cheap; grazing: expensive (capped)
     return np.argsort(-cost.reshape(-1), kind="stable").astype(np.uint32)
+
+
+def world_file_info(path: str) -> "N.WorldInfo":
+    """Header of a brickmap file written by :meth:`Context.save_world` (needs no GPU)."""
+    info = N.WorldInfo()
+    N.check(N.load().vxrt_world_file_info(os.fsencode(path), C.byref(info)))
+    return info
 
 
 def compact_rows(height: int, strip_rows: int, strip_count: int, strip_index: int) -> int:
@@ -120,6 +128,15 @@ class Context:
         info = N.WorldInfo()
         N.check(self._L.vxrt_world_info_get(self._h, C.byref(info)))
         return info
+
+    def save_world(self, path: str) -> None:
+        """Write the resident brickmap to a file (format: include/vxrt.h, "brickmap file")."""
+        N.check(self._L.vxrt_save_world(self._h, os.fsencode(path)))
+
+    def load_world(self, path: str) -> "N.WorldInfo":
+        """Replace the resident brickmap by the one in ``path`` (validated while it streams into HBM)."""
+        N.check(self._L.vxrt_load_world(self._h, os.fsencode(path)))
+        return self.world_info()
 
     def download_world(self, with_pool: bool = True):
         info = self.world_info()
