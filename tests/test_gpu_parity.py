@@ -270,7 +270,8 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
 
 
 @pytest.mark.parametrize("gen,shape,factor", [(0, (128, 128, 128), 16), (2, (256, 256, 256), 32),
-                                              (1, (128, 128, 128), 16), (2, (64, 64, 128), 8)])
+                                              (1, (128, 128, 128), 16), (2, (64, 64, 128), 8),
+                                              (1, (512, 64, 64), 8)])
 def test_device_world_builder_matches_oracle(eng, vxo, gen, shape, factor):
     """vxrt_build_world_procedural produces the oracle's tables bit for bit (PERLIN_REF included: every float
     op in the generator is exactly specified)."""

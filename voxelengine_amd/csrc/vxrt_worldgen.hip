@@ -99,7 +99,14 @@ __device__ float g_fbm(float x, float y, float z)  // repeaterPerlin(pos,1,_,32,
     float acc = 0.0f, amp = 1.0f, scale = 1.0f;
     for (int i = 0; i < 32; ++i) {
         int seed = (int)((uint32_t)(i + 38) * 27389482u);
-        acc += g_perlin3(x * scale, y * scale, z * scale, seed) * amp;
+        // `scale` is an exact power of two, so once all three scaled coordinates are integers they stay integers
+        // in every later octave; there every fraction and fade weight is 0 and the octave adds exactly +-0.
+        // Stopping here gives the bits of the full 32-octave sum (oracle/vxo_world.c runs all 32) at about half
+        // the work for coordinates in the thousands.
+        const float sx = x * scale, sy = y * scale, sz = z * scale;
+        if (sx == floorf(sx) && sy == floorf(sy) && sz == floorf(sz))
+            break;
+        acc += g_perlin3(sx, sy, sz, seed) * amp;
         scale *= 2.0f;
         amp *= 0.5f;
     }
@@ -150,10 +157,13 @@ __device__ __forceinline__ bool g_solid(int x, int y, int z, int Y)
 // its packed extents to ext[cell] and any[cell]
 template <int GEN>
 __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scratch, uint32_t* __restrict__ ext,
-                                                     uint8_t* __restrict__ any, int ctw, int cth, int f, int Y)
+                                                     uint8_t* __restrict__ any, int ctw, int cth, int f, int Y,
+                                                     uint32_t ncells)
 {
     __shared__ int red[7];  // min xyz, max xyz, any
-    const uint32_t cell = blockIdx.x;
+    const uint32_t cell = blockIdx.x + blockIdx.y * gridDim.x;  // 2-D grid: more cells than one grid axis holds
+    if (cell >= ncells)
+        return;
     // inverse of the tiled index for the brick cell (GetPositionFromSampleIndex, VolumeRaytracer.cuh:138-171)
     const uint32_t tile = cell >> 9, in = cell & 511u;
     const int bx = (int)((tile % (uint32_t)ctw) * 8u + (in & 7u));
@@ -167,26 +177,27 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
         red[6] = 0;
     __syncthreads();
 
+    // One voxel per lane: a wave's 64 consecutive bits are one z-slice (8x8) of one 8^3 tile of the brick, and the
+    // ballot mask IS that uint64 of the bit image.  Every lane is busy for every brick edge (f = 8: 512 voxels on
+    // 256 threads; the earlier one-word-per-lane form left 240 of them idle there).
     const int ftw = f >> 3;
-    const uint32_t words = (uint32_t)(f * f * f) >> 5;
+    const uint32_t words = (uint32_t)(f * f * f) >> 5, nbits = words << 5;
     int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mnz = 0x7FFFFFFF, mxx = -1, mxy = -1, mxz = -1;
-    uint32_t* dst = scratch + (size_t)cell * words;
-    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) {
-        const uint32_t bt = w >> 4;            // tile inside the brick (16 words per tile)
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(scratch + (size_t)cell * words);
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t o = threadIdx.x; o < nbits; o += blockDim.x) {  // nbits is a multiple of 512: whole waves iterate
+        const uint32_t bt = o >> 9;  // tile inside the brick
         const int tx = (int)(bt % (uint32_t)ftw), ty = (int)((bt / (uint32_t)ftw) % (uint32_t)ftw),
                   tz = (int)(bt / (uint32_t)(ftw * ftw));
-        const uint32_t base = (w & 15u) << 5;  // first bit of this word inside the tile
-        uint32_t bits = 0;
-        for (uint32_t k = 0; k < 32u; ++k) {
-            uint32_t o = base + k;
-            int lx = tx * 8 + (int)(o & 7u), ly = ty * 8 + (int)((o >> 3) & 7u), lz = tz * 8 + (int)(o >> 6);
-            if (g_solid<GEN>(bx * f + lx, by * f + ly, bz * f + lz, Y)) {
-                bits |= 1u << k;
-                mnx = min(mnx, lx); mny = min(mny, ly); mnz = min(mnz, lz);
-                mxx = max(mxx, lx); mxy = max(mxy, ly); mxz = max(mxz, lz);
-            }
+        const int lx = tx * 8 + (int)(o & 7u), ly = ty * 8 + (int)((o >> 3) & 7u), lz = tz * 8 + (int)((o >> 6) & 7u);
+        const bool solid = g_solid<GEN>(bx * f + lx, by * f + ly, bz * f + lz, Y);
+        const unsigned long long mask = __ballot(solid);
+        if (lane == 0)
+            dst[o >> 6] = mask;
+        if (solid) {
+            mnx = min(mnx, lx); mny = min(mny, ly); mnz = min(mnz, lz);
+            mxx = max(mxx, lx); mxy = max(mxy, ly); mxz = max(mxz, lz);
         }
-        dst[w] = bits;
     }
     if (mxx >= 0) {
         atomicMin(&red[0], mnx); atomicMin(&red[1], mny); atomicMin(&red[2], mnz);
@@ -207,9 +218,11 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
 // pack non-empty bricks into the pool, 16 bytes per lane, and write the cell_meta records
 __global__ __launch_bounds__(256) void k_pack_bricks(const uint4* __restrict__ scratch, const uint32_t* __restrict__ slot,
                                                      const uint32_t* __restrict__ ext, uint4* __restrict__ pool,
-                                                     uint2* __restrict__ meta, uint32_t vecs_per_brick)
+                                                     uint2* __restrict__ meta, uint32_t vecs_per_brick, uint32_t ncells)
 {
-    const uint32_t cell = blockIdx.x;
+    const uint32_t cell = blockIdx.x + blockIdx.y * gridDim.x;
+    if (cell >= ncells)
+        return;
     const uint32_t s = slot[cell];
     if (threadIdx.x == 0)
         meta[cell] = make_uint2(s, ext[cell]);
@@ -275,16 +288,17 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
     WG_HIP(hipMalloc((void**)&d_scratch, ncells * bw * sizeof(uint32_t)));
     WG_HIP(hipMalloc((void**)&d_ext, ncells * sizeof(uint32_t)));
     WG_HIP(hipMalloc((void**)&d_any, ncells));
-    dim3 grid((unsigned)ncells), block(256);
+    const unsigned gx = ncells > (1u << 20) ? (1u << 20) : (unsigned)ncells;
+    dim3 grid(gx, (unsigned)((ncells + gx - 1) / gx)), block(256);
     if (generator == VXRT_GEN_HASH_HEIGHTFIELD)
         hipLaunchKernelGGL(k_fill_bricks<VXRT_GEN_HASH_HEIGHTFIELD>, grid, block, 0, 0, d_scratch, d_ext, d_any, cd[0] / 8,
-                           cd[1] / 8, factor, Y);
+                           cd[1] / 8, factor, Y, (uint32_t)ncells);
     else if (generator == VXRT_GEN_PERLIN_REF)
         hipLaunchKernelGGL(k_fill_bricks<VXRT_GEN_PERLIN_REF>, grid, block, 0, 0, d_scratch, d_ext, d_any, cd[0] / 8,
-                           cd[1] / 8, factor, Y);
+                           cd[1] / 8, factor, Y, (uint32_t)ncells);
     else
         hipLaunchKernelGGL(k_fill_bricks<VXRT_GEN_INT_TERRAIN>, grid, block, 0, 0, d_scratch, d_ext, d_any, cd[0] / 8,
-                           cd[1] / 8, factor, Y);
+                           cd[1] / 8, factor, Y, (uint32_t)ncells);
     WG_HIP(hipGetLastError());
     WG_HIP(hipDeviceSynchronize());
 
@@ -307,7 +321,7 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
         return rc;
     }
     hipLaunchKernelGGL(k_pack_bricks, grid, block, 0, 0, (const uint4*)d_scratch, d_slot, d_ext, (uint4*)d_pool, d_meta,
-                       (uint32_t)(bw / 4));
+                       (uint32_t)(bw / 4), (uint32_t)ncells);
     WG_HIP(hipGetLastError());
     uint64_t nwords = (ncells + 31) / 32;
     hipLaunchKernelGGL(k_coarse_bits, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, 0, d_any, d_coarse, ncells);
