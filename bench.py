@@ -32,6 +32,8 @@ WORKLOADS = {
     "c2_1k_1080p_primary": (1024, 256, 1024, 32, 1, 1920, 1080, 0, 0),
     "c4_8k_4k_shadow_bounce": (8192, 512, 8192, 32, 1, 3840, 2160, 1, 1),
     "dev_small": (1024, 256, 1024, 32, 2, 1920, 1080, 1, 1),
+    # configs[4]'s world and frame with the reference's ray set (its second bounce is an extension, not built)
+    "c5_16k_4k_shadow_bounce": (16384, 1024, 16384, 32, 1, 3840, 2160, 1, 1),
     # configs[2] with the 2-D tester's brick edge ("f=8 reported as a variant")
     "c3_f8_variant": (8192, 512, 8192, 8, 1, 1920, 1080, 1, 1),
     # ablations of configs[2] for kernel work (not bench lines)
