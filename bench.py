@@ -59,6 +59,7 @@ def parse():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
+    ap.add_argument("--bounce-depth", type=int, default=1, help="2 = second bounce (BASELINE config 5; extension beyond the reference)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and the gather goes through gloo/host memory, to "
                          "exercise the N>1 code path on a one-GPU box (numbers are meaningless)")
@@ -116,7 +117,7 @@ def main():
 
     def opts(frame_number, stats=False):
         return vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, bounce_all_hits=bool(args.bounce_all_hits),
-                                frame_number=frame_number, strip_rows=plan.strip_rows, strip_count=world,
+                                bounce_depth=args.bounce_depth, frame_number=frame_number, strip_rows=plan.strip_rows, strip_count=world,
                                 strip_index=rank, compact=world > 1, collect_stats=stats)
 
     def deinterleave(sh, fr):
@@ -204,8 +205,9 @@ def main():
             "config": {
                 "workload": args.workload, "world": [X, Y, Z], "factor": F,
                 "generator": ["hash_heightfield", "perlin_ref", "int_terrain"][gen], "resolution": [W, H],
-                "rays": "primary + shadow per hit + %d bounce sample(s), gate=%s" % (
-                    bounce, "all-hits" if args.bounce_all_hits else "reference lDot==0"),
+                "rays": "primary + shadow per hit + %d bounce sample(s), gate=%s%s" % (
+                    bounce, "all-hits" if args.bounce_all_hits else "reference lDot==0",
+                    ", second bounce (extension beyond the reference)" if args.bounce_depth >= 2 else ""),
                 "cameras": [c[0] for c in CAMERAS], "sharding": "interleaved %d-row strips, gather to rank 0" % plan.strip_rows
                 if world > 1 else "none", "rays_per_step": round(rays_total / args.steps, 1),
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
@@ -222,7 +224,7 @@ def main():
             full = torch.zeros_like(frame)
             ctx.RenderScreen(W, H, full, pos, f, u, r, vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,
                                                                    bounce_all_hits=bool(args.bounce_all_hits),
-                                                                   frame_number=i + 1))
+                                                                   bounce_depth=args.bounce_depth, frame_number=i + 1))
             torch.cuda.synchronize()
             result["rehearsal"] = {"gathered_frame_equals_single_gpu_frame": bool(torch.equal(full, frame)),
                                    "note": "all ranks on one GPU over gloo: value is not a measurement"}
@@ -268,7 +270,7 @@ def cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts):
         name, pos, f, u, r = cams[i % len(cams)]
         names.append(name)
         p = vxo.make_params(W, H, pos, f, u, r, frame_number=i + 1, shadow=shadow, bounce_samples=bounce,
-                            bounce_all_hits=args.bounce_all_hits)
+                            bounce_all_hits=args.bounce_all_hits, bounce_depth=args.bounce_depth)
         t0 = time.perf_counter()
         out = world.render(p, fb=np.zeros((H, W, 4), np.uint8), want_hit=True, nthreads=cores)
         secs += time.perf_counter() - t0

@@ -28,6 +28,7 @@ struct RenderSwitches {
     bool ShadowRay = false;
     int BounceSamples = 0;
     bool BounceAllHits = false;
+    int BounceDepth = 1;  // 2: second bounce, an extension beyond the reference (include/vxrt.h)
 };
 void SetRenderSwitches(const RenderSwitches& s);
 

@@ -143,6 +143,10 @@ typedef struct vxrt_render_flags {
     int32_t shadow;          /* 1 = shadow ray of Renderer.cu:97-102 enabled */
     int32_t bounce_samples;  /* `samples` of Renderer.cu:123 */
     int32_t bounce_all_hits; /* 0 = reference gate `lDot == 0` (Renderer.cu:121); 1 = every hit pixel */
+    int32_t bounce_depth;    /* <= 1 (default): the reference's one occlusion ray per sample.  2: EXTENSION beyond the
+                                reference (BASELINE config 5): a sample ray that hits spawns one more 8-step ray from
+                                its hit point, built like the first (outward normal there, seed + 500); a miss of
+                                that ray adds 0.5 to the sample sum */
     int32_t ortho;           /* `#define ORTHO` (Renderer.cuh:13) */
     int64_t frame_number;    /* >= 0: value the kernel sees as FrameNumber; < 0: the context's own
                                 counter with the reference's post-copy increment (Renderer.cu:310,322) */

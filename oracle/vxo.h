@@ -154,6 +154,9 @@ typedef struct vxo_render_params {
     int shadow;                     /* 1: shadow ray enabled (Renderer.cu:102 un-commented) */
     int bounce_samples;             /* `samples` at Renderer.cu:123 */
     int bounce_all_hits;            /* 0: reference gate lDot==0 (Renderer.cu:121); 1: every hit pixel */
+    int bounce_depth;               /* <= 1: the reference's single occlusion ray per sample.  2: EXTENSION beyond the
+                                       reference (BASELINE config 5): a sample ray that hits spawns one more 8-step ray
+                                       from its hit point (outward normal, seed + 500); a miss of that ray adds 0.5 */
     float origin[3], fwd[3], up[3], right[3];
     vxo_env env;
     /* rows [row_begin,row_end) of the frame are rendered (multi-GPU strips); 0,height = all */

@@ -48,7 +48,7 @@ class RenderParams(C.Structure):
         ("width", C.c_uint32), ("height", C.c_uint32), ("frame_number", C.c_uint32),
         ("fov_deg", C.c_float), ("ortho_size", C.c_float * 2), ("ortho", C.c_int), ("mode", C.c_int),
         ("checkerboard", C.c_int), ("shadow", C.c_int), ("bounce_samples", C.c_int),
-        ("bounce_all_hits", C.c_int),
+        ("bounce_all_hits", C.c_int), ("bounce_depth", C.c_int),
         ("origin", C.c_float * 3), ("fwd", C.c_float * 3), ("up", C.c_float * 3), ("right", C.c_float * 3),
         ("env", Env), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
     ]
@@ -285,13 +285,14 @@ def dense_from_voxels(vox: np.ndarray) -> np.ndarray:
 def make_params(width, height, origin, fwd, up, right, *, frame_number=1, fov=90.0, mode=MODE_SHADED,
                 checkerboard=0, shadow=0, bounce_samples=0, bounce_all_hits=0, ortho=0,
                 ortho_size=(10.0, 10.0), light_dir=None, light_color=(2, 2, 2), ambient=(0.5, 0.5, 0.5),
-                row_begin=0, row_end=0) -> RenderParams:
+                row_begin=0, row_end=0, bounce_depth=1) -> RenderParams:
     p = RenderParams()
     p.width, p.height, p.frame_number = width, height, frame_number
     p.fov_deg = fov
     p.ortho_size = (C.c_float * 2)(*ortho_size)
     p.ortho, p.mode, p.checkerboard = ortho, mode, checkerboard
     p.shadow, p.bounce_samples, p.bounce_all_hits = shadow, bounce_samples, bounce_all_hits
+    p.bounce_depth = bounce_depth
     p.origin, p.fwd, p.up, p.right = _f3(origin), _f3(fwd), _f3(up), _f3(right)
     if light_dir is None:  # VoxelApp/main.cu:59-60: normalize((1,1,1)) in float
         inv = np.float32(1.0) / np.sqrt(np.float32(3.0), dtype=np.float32)

@@ -153,8 +153,23 @@ static v3 shade(frame_ctx *c, uint32_t tx, uint32_t ty, v3 cam, v3 normal, v3 po
             v3 sp = add(position, scl(normal, 0.01f)), sn;
             int st;
             c->stats.bounce_rays += 1;
-            if (!trace(c, 8, sp, sd, &st, &sn, &sp, NULL))
+            if (!trace(c, 8, sp, sd, &st, &sn, &sp, NULL)) {
                 occl += 1.0f;
+            } else if (p->bounce_depth >= 2) {
+                /* extension (not in the reference): second diffuse bounce from the sample ray's hit point `sp`,
+                 * built exactly like the first one around the outward normal there */
+                v3 n2 = mk(-sn.x, -sn.y, -sn.z);
+                uint32_t s2 = si + 500u;
+                v3 d2 = mk(vxo_random_float(s2) * 2 - 1, vxo_random_float(s2 * 10u) * 2 - 1,
+                           vxo_random_float(s2 * 100u) * 2 - 1);
+                d2 = unit(d2);
+                if (dot3(d2, n2) < 0)
+                    d2 = bounce_dir(d2, n2);
+                v3 o2 = add(sp, scl(n2, 0.01f)), sn2;
+                c->stats.bounce_rays += 1;
+                if (!trace(c, 8, o2, d2, &st, &sn2, &o2, NULL))
+                    occl += 0.5f;
+            }
         }
         if (samples > 0)
             occl /= (float)samples;

@@ -85,6 +85,8 @@ def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
         _assert_frame_equal(*_render_both(eng, vxo, w, 160, 90, "D", frame_number=2, mode=1, checkerboard=1))
         _assert_frame_equal(*_render_both(eng, vxo, w, 128, 96, "A", ortho=1, ortho_size=(60.0, 60.0), shadow=1))
         _assert_frame_equal(*_render_both(eng, vxo, w, 131, 77, "C"))
+        _assert_frame_equal(*_render_both(eng, vxo, w, 144, 80, "A", frame_number=6, shadow=1, bounce_samples=2,
+                                          bounce_all_hits=1, bounce_depth=2))
     finally:
         ctx.set_kernel_variant(default)
 
@@ -122,6 +124,7 @@ def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
     opts = vx.RenderOptions(mode=kw.get("mode", 0), checkerboard=bool(kw.get("checkerboard", 0)),
                             shadow=bool(kw.get("shadow", 0)), bounce_samples=kw.get("bounce_samples", 0),
                             bounce_all_hits=bool(kw.get("bounce_all_hits", 0)), ortho=bool(kw.get("ortho", 0)),
+                            bounce_depth=kw.get("bounce_depth", 1),
                             frame_number=frame_number, collect_stats=True)
     ctx.frame_stats()   # counters accumulate until read: start this frame from zero
     ctx.RenderScreen(W, H, d_fb, pos, f, u, r, opts, color_aov=d_col, hit_aov=d_hit)
@@ -157,6 +160,22 @@ def test_render_shadow_and_bounce(eng, vxo, cam, gate):
                                          bounce_all_hits=gate)
     _assert_frame_equal(cpu, fb, col, hit, st)
     assert st.shadow_rays == st.primary_hits and st.bounce_rays > 0
+
+
+@pytest.mark.parametrize("cam,gate", [("A", 0), ("B", 1), ("D", 1)])
+def test_render_second_bounce_extension(eng, vxo, cam, gate):
+    """bounce_depth = 2 (BASELINE config 5; an extension beyond the reference, defined in include/vxrt.h and restated
+    in oracle/vxo_render.c): sample rays that hit spawn one more ray; more bounce rays than with depth 1, same bits
+    as the oracle."""
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(eng[1], w)
+    kw = dict(frame_number=4, shadow=1, bounce_samples=2, bounce_all_hits=gate)
+    one = _render_both(eng, vxo, w, 192, 108, cam, **kw)
+    two = _render_both(eng, vxo, w, 192, 108, cam, bounce_depth=2, **kw)
+    _assert_frame_equal(*one)
+    _assert_frame_equal(*two)
+    assert two[4].bounce_rays > one[4].bounce_rays and two[4].primary_rays == one[4].primary_rays
+    assert not np.array_equal(one[1], two[1])
 
 
 @pytest.mark.parametrize("frame", [0, 1])

@@ -55,7 +55,7 @@ class FrameStats(C.Structure):
 class RenderFlags(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("mode", C.c_int32), ("checkerboard", C.c_int32), ("shadow", C.c_int32),
-        ("bounce_samples", C.c_int32), ("bounce_all_hits", C.c_int32), ("ortho", C.c_int32),
+        ("bounce_samples", C.c_int32), ("bounce_all_hits", C.c_int32), ("bounce_depth", C.c_int32), ("ortho", C.c_int32),
         ("frame_number", C.c_int64),
         ("strip_rows", C.c_int32), ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("compact", C.c_int32),
         ("collect_stats", C.c_int32), ("tile_schedule", C.c_int32),

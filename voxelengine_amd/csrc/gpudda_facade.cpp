@@ -334,6 +334,7 @@ void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_t
     fl.shadow = g_switches.ShadowRay;
     fl.bounce_samples = g_switches.BounceSamples;
     fl.bounce_all_hits = g_switches.BounceAllHits;
+    fl.bounce_depth = g_switches.BounceDepth;
     fl.frame_number = -1;  // the context's counter: copy, then increment (Renderer.cu:310,322)
     const float o[3] = {origin.x, origin.y, origin.z}, f[3] = {fwd.x, fwd.y, fwd.z}, u[3] = {up.x, up.y, up.z},
                 r[3] = {right.x, right.y, right.z};

@@ -469,6 +469,7 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
     A.shadow = fl->shadow ? 1 : 0;
     A.bounce_samples = fl->bounce_samples < 0 ? 0 : fl->bounce_samples;
     A.bounce_all_hits = fl->bounce_all_hits ? 1 : 0;
+    A.bounce_depth = fl->bounce_depth >= 2 ? 2 : 1;
     A.ortho = fl->ortho ? 1 : 0;
     A.strip_rows = fl->strip_rows > 0 ? fl->strip_rows : 16;
     A.strip_count = fl->strip_count > 1 ? fl->strip_count : 1;

@@ -103,8 +103,21 @@ __device__ f3 shade(const RenderArgs& A, uint32_t tx, uint32_t ty, f3 cam, f3 no
             TraceResult tr;
             n_bounce += 1;
             trace_direct(A.W, 8, sp, sd, tr, cnt);
-            if (!tr.hit)
+            if (!tr.hit) {
                 occl += 1.0f;
+            } else if (A.bounce_depth >= 2) {  // extension: second bounce from the sample ray's hit point
+                const f3 n2 = mk3(-tr.normal.x, -tr.normal.y, -tr.normal.z);
+                const uint32_t s2 = si + 500u;
+                f3 d2 = mk3(random_float(s2) * 2 - 1, random_float(s2 * 10u) * 2 - 1, random_float(s2 * 100u) * 2 - 1);
+                d2 = unit3(d2);
+                if (dot3(d2, n2) < 0)
+                    d2 = reflect3(d2, n2);
+                TraceResult t2;
+                n_bounce += 1;
+                trace_direct(A.W, 8, tr.pos + n2 * 0.01f, d2, t2, cnt);
+                if (!t2.hit)
+                    occl += 0.5f;
+            }
         }
         if (samples > 0)
             occl /= (float)samples;
@@ -393,6 +406,22 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
                 if (!tb.hit)
                     occl += 1.0f;
             }
+            if (A.bounce_depth >= 2) {  // extension: second bounce from the sample ray's hit point
+                const bool again = gate && tb.hit;
+                const f3 n2 = mk3(-tb.normal.x, -tb.normal.y, -tb.normal.z);
+                const uint32_t s2 = si + 500u;
+                f3 d2 = mk3(random_float(s2) * 2 - 1, random_float(s2 * 10u) * 2 - 1, random_float(s2 * 100u) * 2 - 1);
+                d2 = unit3(d2);
+                if (dot3(d2, n2) < 0)
+                    d2 = reflect3(d2, n2);
+                TraceResult t2;
+                trace_wave<STATS>(A.W, 8, again, tb.pos + n2 * 0.01f, d2, t2, cnt);
+                if (again) {
+                    n_bounce += 1;
+                    if (!t2.hit)
+                        occl += 0.5f;
+                }
+            }
         }
         if (gate) {
             if (samples > 0)
@@ -522,10 +551,15 @@ void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t str
         const unsigned ntiles = ((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u);
         const unsigned waves = ntiles < A.persistent_waves ? ntiles : A.persistent_waves;
         (void)hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
-        if (stats)
-            hipLaunchKernelGGL(k_render_persist<true>, dim3(waves), dim3(64), lds, stream, A);
+        const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
+        if (stats && second_bounce)
+            hipLaunchKernelGGL((k_render_persist<true, true>), dim3(waves), dim3(64), lds, stream, A);
+        else if (stats)
+            hipLaunchKernelGGL((k_render_persist<true, false>), dim3(waves), dim3(64), lds, stream, A);
+        else if (second_bounce)
+            hipLaunchKernelGGL((k_render_persist<false, true>), dim3(waves), dim3(64), lds, stream, A);
         else
-            hipLaunchKernelGGL(k_render_persist<false>, dim3(waves), dim3(64), lds, stream, A);
+            hipLaunchKernelGGL((k_render_persist<false, false>), dim3(waves), dim3(64), lds, stream, A);
         return;
     }
     if (variant == 1) {

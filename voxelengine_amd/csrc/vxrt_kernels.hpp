@@ -41,6 +41,7 @@ struct RenderArgs {
     f3 origin, fwd, up, right;
     f3 light_dir, light_color, ambient;
     int mode, checkerboard, shadow, bounce_samples, bounce_all_hits, ortho;
+    int bounce_depth;  // 2: extension beyond the reference, a sample ray that hits spawns one more ray (include/vxrt.h)
     int strip_rows, strip_count, strip_index, compact;
     uint8_t* fb;
     float* color_aov;

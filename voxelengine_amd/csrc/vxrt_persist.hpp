@@ -21,7 +21,7 @@
 
 namespace vxrt {
 
-enum : uint32_t { PX_NONE = 0u, PX_PRIMARY = 1u, PX_SHADOW = 2u, PX_BOUNCE = 3u };
+enum : uint32_t { PX_NONE = 0u, PX_PRIMARY = 1u, PX_SHADOW = 2u, PX_BOUNCE = 3u, PX_BOUNCE2 = 4u };
 
 struct PixelCoords {
     uint32_t tx, ty;  // launch coordinates of the reference's thread (crosshair, RNG seed)
@@ -82,7 +82,9 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, int x, int y, f3
 #ifndef VXRT_PERSIST_OCC
 #define VXRT_PERSIST_OCC 4  // waves per SIMD the register budget is sized for (128 VGPRs)
 #endif
-template <bool STATS>
+// BOUNCE2: the second-bounce extension (bounce_depth 2) is compiled into its own instantiation -- carried as a
+// run-time branch it cost the reference ray set 29 more spilled VGPRs and 4 % of its speed.
+template <bool STATS, bool BOUNCE2>
 __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderArgs A)
 {
     const WorldView& W = A.W;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 camera_ray(A, pc.x, pc.y, origin, ray);
                 TraceResult r;
                 T.result(W, r);
-                bool finalize = false, do_shade = false, shadowed = false, bounce = false;
+                bool finalize = false, do_shade = false, shadowed = false, bounce = false, bounce2 = false;
                 if (stage == PX_PRIMARY) {
                     pcode = (r.hit && r.steps == 0) ? T.entry_code : T.out_code;
                     p_steps = r.steps;
@@ -235,32 +237,40 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     } else {
                         finalize = true;  // gate closed, or samples == 0: occlusion = 1 (Renderer.cu:159-164)
                     }
-                } else if (stage == PX_BOUNCE) {
+                } else if (stage == PX_BOUNCE || (BOUNCE2 && stage == PX_BOUNCE2)) {
                     if (!r.hit)
-                        occl += 1.0f;
-                    sample += 1;
-                    if (sample < A.bounce_samples) {
-                        bounce = true;
-                    } else {
-                        occl /= (float)A.bounce_samples;
-                        color = color * occl;
-                        stage = PX_PRIMARY;
-                        finalize = true;
+                        occl += stage == PX_BOUNCE ? 1.0f : 0.5f;
+                    // extension beyond the reference (bounce_depth 2): a sample ray that hits spawns one more ray
+                    bounce2 = BOUNCE2 && stage == PX_BOUNCE && r.hit;
+                    if (!bounce2) {
+                        sample += 1;
+                        if (sample < A.bounce_samples) {
+                            bounce = true;
+                        } else {
+                            occl /= (float)A.bounce_samples;
+                            color = color * occl;
+                            stage = PX_PRIMARY;
+                            finalize = true;
+                        }
                     }
                 }
-                if (bounce) {  // one sample of Renderer.cu:128-142
+                if (bounce || bounce2) {  // one sample of Renderer.cu:128-142, around the primary hit or the sample ray's
                     const uint32_t seed = pc.ty * A.width + pc.tx;
-                    const uint32_t si = seed + (uint32_t)sample * 1000u + (A.frame_number + 1u) * 1000u;
+                    const uint32_t si = seed + (uint32_t)sample * 1000u + (A.frame_number + 1u) * 1000u + (bounce2 ? 500u : 0u);
+                    const f3 bn = mk3(bounce2 ? -r.normal.x : normal.x, bounce2 ? -r.normal.y : normal.y,
+                                      bounce2 ? -r.normal.z : normal.z);
+                    const f3 bo = mk3(bounce2 ? r.pos.x : position.x, bounce2 ? r.pos.y : position.y,
+                                      bounce2 ? r.pos.z : position.z);
                     f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
                     sd = unit3(sd);
-                    if (dot3(sd, normal) < 0)
-                        sd = reflect3(sd, normal);
+                    if (dot3(sd, bn) < 0)
+                        sd = reflect3(sd, bn);
                     n_bounce += 1;
                     launch = true;
-                    l_origin = position + normal * 0.01f;
+                    l_origin = bo + bn * 0.01f;
                     l_dir = sd;
                     l_max = 8;
-                    stage = PX_BOUNCE;
+                    stage = bounce2 ? PX_BOUNCE2 : PX_BOUNCE;
                 }
                 if (finalize) {
                     store_pixel(pc, origin, ray, stage != PX_NONE, normal, position, color);

@@ -69,6 +69,7 @@ class RenderOptions:
     shadow: bool = False
     bounce_samples: int = 0
     bounce_all_hits: bool = False
+    bounce_depth: int = 1           # 2: extension beyond the reference (second bounce, include/vxrt.h)
     ortho: bool = False
     frame_number: int = -1          # < 0: context counter with the reference's post-copy increment
     strip_rows: int = 16
@@ -175,6 +176,7 @@ class Context:
         fl.strip_rows, fl.strip_count, fl.strip_index = int(o.strip_rows), int(o.strip_count), int(o.strip_index)
         fl.compact, fl.collect_stats = int(o.compact), int(o.collect_stats)
         fl.tile_schedule = int(o.tile_schedule)
+        fl.bounce_depth = int(o.bounce_depth)
         fl.d_color_aov = _ptr(color_aov)
         fl.d_hit_aov = _ptr(hit_aov)
         fl.d_tile_order = _ptr(tile_order)
