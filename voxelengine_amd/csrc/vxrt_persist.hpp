@@ -162,8 +162,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             dg_iters += 1;
             dg_walk += (unsigned long long)n_walk;
             dg_drain += drained ? 1ull : 0ull;
-            const bool r_next = vote_run(n_next, n_walk + n_box + n_end), r_end = vote_run(n_end, n_walk + n_box),
-                       r_box = vote_run(n_box, n_walk);
+            const bool r_next = vote_run(n_next, n_walk + n_box + n_end, VXRT_VOTE_NEXT),
+                       r_end = vote_run(n_end, n_walk + n_box, VXRT_VOTE_END), r_box = vote_run(n_box, n_walk, VXRT_VOTE_BOX);
             dg_runs[0] += r_next ? 1u : 0u;
             dg_runs[1] += r_end ? 1u : 0u;
             dg_runs[2] += r_box ? 1u : 0u;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
         // launch; one begin_ray at the end of the phase serves them all (its 7 divisions + square root are the
         // expensive part of this phase).
-        if (vote_run(n_next, n_walk + n_box + n_end)) {
+        if (vote_run(n_next, n_walk + n_box + n_end, VXRT_VOTE_NEXT)) {
             bool launch = false;
             f3 l_origin = mk3(0, 0, 0), l_dir = mk3(1, 0, 0);
             int l_max = kMaxSteps;
@@ -336,11 +336,11 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 T.st = ST_IDLE;
         }
 
-        if (vote_run(n_end, n_walk + n_box)) {
+        if (vote_run(n_end, n_walk + n_box, VXRT_VOTE_END)) {
             if (T.st == ST_END)
                 T.phase_end(W);
         }
-        if (vote_run(n_box, n_walk)) {
+        if (vote_run(n_box, n_walk, VXRT_VOTE_BOX)) {
             if (T.st == ST_BOX)
                 T.phase_box(W);
         }

@@ -42,7 +42,22 @@ __device__ __forceinline__ f3 normal_decode(uint32_t c)
 #ifndef VXRT_VOTE_NUM
 #define VXRT_VOTE_NUM 4
 #endif
-__device__ __forceinline__ bool vote_run(int parked, int others) { return parked > 0 && parked * VXRT_VOTE_NUM >= others; }
+__device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_VOTE_NUM)
+{
+    return parked > 0 && parked * num >= others;
+}
+// Per-phase thresholds, from a sweep on the bench workload: the expensive phases (ray finished ~450 VALU, end of
+// walk ~130) wait until their lanes are a third of the live ones, the cheap tight-box test (~60) runs at a fifth.
+// (2,2,4) against (4,4,4): +2 % at 1080p, +5 % at 4K; waiting longer (1) or running sooner (6..12) both lose.
+#ifndef VXRT_VOTE_NEXT
+#define VXRT_VOTE_NEXT 2
+#endif
+#ifndef VXRT_VOTE_END
+#define VXRT_VOTE_END 2
+#endif
+#ifndef VXRT_VOTE_BOX
+#define VXRT_VOTE_BOX 4
+#endif
 
 // One lane's ray: Raytrace-level state (:359-384), the current DDARayTraversal walk (:178-232) and the coarse
 // results that outlive the coarse walk (:399-429,:438-488).  All members live in registers.
@@ -384,14 +399,14 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
         if (STATS) {
             cnt.iters += 1;
-            cnt.end_runs += vote_run(n_end, n_walk + n_box) ? 1u : 0u;
-            cnt.box_runs += vote_run(n_box, n_walk) ? 1u : 0u;
+            cnt.end_runs += vote_run(n_end, n_walk + n_box, VXRT_VOTE_END) ? 1u : 0u;
+            cnt.box_runs += vote_run(n_box, n_walk, VXRT_VOTE_BOX) ? 1u : 0u;
         }
-        if (vote_run(n_end, n_walk + n_box)) {
+        if (vote_run(n_end, n_walk + n_box, VXRT_VOTE_END)) {
             if (T.st == ST_END)
                 T.phase_end(W);
         }
-        if (vote_run(n_box, n_walk)) {
+        if (vote_run(n_box, n_walk, VXRT_VOTE_BOX)) {
             if (T.st == ST_BOX)
                 T.phase_box(W);
         }
