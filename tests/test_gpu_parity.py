@@ -219,7 +219,7 @@ def test_context_frame_counter_matches_reference_increment(eng, vxo):
     c2.close()
 
 
-@pytest.mark.parametrize("count,rows", [(2, 16), (8, 16), (3, 8)])
+@pytest.mark.parametrize("count,rows", [(2, 16), (8, 16), (3, 8), (4, 12), (5, 1)])
 def test_strip_sharding_reassembles_the_frame(eng, vxo, count, rows):
     """Each shard renders its interleaved strips into a packed buffer; de-interleaving the shard buffers gives
     the single-GPU frame byte for byte."""

@@ -475,6 +475,10 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
     A.strip_count = fl->strip_count > 1 ? fl->strip_count : 1;
     A.strip_index = fl->strip_index;
     A.compact = fl->compact ? 1 : 0;
+    A.strip_shift = -1;
+    for (int b = 0; b < 31; ++b)
+        if (A.strip_rows == (1 << b))
+            A.strip_shift = b;
     // launch shape: RenderScreen halves the rows under checkerboard (Renderer.cu:311-316); a shard
     // without checkerboard launches only its own rows
     if (A.checkerboard)

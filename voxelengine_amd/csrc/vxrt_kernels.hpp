@@ -43,6 +43,7 @@ struct RenderArgs {
     int mode, checkerboard, shadow, bounce_samples, bounce_all_hits, ortho;
     int bounce_depth;  // 2: extension beyond the reference, a sample ray that hits spawns one more ray (include/vxrt.h)
     int strip_rows, strip_count, strip_index, compact;
+    int strip_shift;  // log2(strip_rows) when that is a power of two, else -1
     uint8_t* fb;
     float* color_aov;
     long long* hit_aov;

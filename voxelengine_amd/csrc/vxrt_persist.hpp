@@ -30,19 +30,27 @@ struct PixelCoords {
     bool live;
 };
 
-// launch (tx,row) -> pixel, shared by all render kernels (Renderer.cu:183-196 + this build's strip sharding)
+// launch (tx,row) -> pixel (Renderer.cu:183-196 + this build's strip sharding)
 __device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_t tx, uint32_t row)
 {
     PixelCoords c;
     c.tx = tx;
     c.ty = row;
+    c.x = (int)tx;
     const bool sharded = A.strip_count > 1;
     if (sharded && !A.checkerboard) {
-        uint32_t strip = (row / (uint32_t)A.strip_rows) * (uint32_t)A.strip_count + (uint32_t)A.strip_index;
-        c.ty = strip * (uint32_t)A.strip_rows + row % (uint32_t)A.strip_rows;
+        // A shard's launch rows are its own frame rows in order: launch row = packed row, the frame row follows from
+        // the strip arithmetic, and ownership holds by construction -- no division by the strip count, and none by the
+        // strip height when it is a power of two (strip_shift >= 0; the default 16 is).
+        const uint32_t sr = (uint32_t)A.strip_rows;
+        const uint32_t q = A.strip_shift >= 0 ? row >> A.strip_shift : row / sr;
+        c.ty = (q * (uint32_t)A.strip_count + (uint32_t)A.strip_index) * sr + (row - q * sr);
+        c.y = (int)c.ty;
+        c.live = row < A.launch_rows && (uint32_t)c.x < A.width && (uint32_t)c.y < A.height;
+        c.out_row = A.compact ? (int)row : c.y;
+        return c;
     }
     c.live = row < A.launch_rows;
-    c.x = (int)tx;
     c.y = (int)c.ty;
     if (A.checkerboard) {
         c.y *= 2;
