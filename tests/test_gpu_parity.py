@@ -288,6 +288,55 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("variant", [2, 0])
+def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
+    """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).
+    Every view must be byte for byte the frame RenderScreen produces for it -- frame, hit-index AOV and colour AOV --
+    for plain, checkerboard (per-view frame numbers) and strip-sharded launches, and equal to the oracle."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    W, H = 724, 412   # 91 x 52 tiles per view: more tiles than waves, ragged edges
+    cams = ["A", "B", "D", "C", "A"]
+    frames = [3, 4, 7, 8, 11]
+    default = ctx.kernel_variant
+    try:
+        ctx.set_kernel_variant(variant)
+        for kw in (dict(shadow=True, bounce_samples=1), dict(shadow=True, bounce_samples=2, bounce_depth=2, checkerboard=True),
+                   dict(mode=1), dict(shadow=True, bounce_samples=1, strip_rows=16, strip_count=3, strip_index=1, compact=True)):
+            rows = vx.compact_rows(H, 16, 3, 1) if kw.get("compact") else H
+            singles, views = [], []
+            ctx.frame_stats()   # counters accumulate until read: start from zero
+            stale =torch.from_numpy(np.random.default_rng(3).integers(0, 255, size=(rows, W, 4), dtype=np.uint8)).cuda()
+            for cam, fn in zip(cams, frames):
+                pos, f, u, r = helpers.camera(cam, w.dims, vxo)
+                fb, hit = stale.clone(), torch.full((rows, W), -7, dtype=torch.int64, device="cuda")
+                col = torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")
+                ctx.RenderScreen(W, H, fb, pos, f, u, r, vx.RenderOptions(frame_number=fn, **kw), color_aov=col, hit_aov=hit)
+                singles.append((fb, hit, col))
+                views.append(dict(fb=stale.clone(), origin=pos, fwd=f, up=u, right=r, frame_number=fn,
+                                  hit_aov=torch.full((rows, W), -7, dtype=torch.int64, device="cuda"),
+                                  color_aov=torch.zeros((rows, W, 3), dtype=torch.float32, device="cuda")))
+            rays_single = ctx.frame_stats().total_rays()
+            ctx.RenderViews(W, H, views, vx.RenderOptions(**kw))
+            assert ctx.frame_stats().total_rays() == rays_single
+            for (fb, hit, col), v in zip(singles, views):
+                assert torch.equal(v["fb"], fb) and torch.equal(v["hit_aov"], hit) and torch.equal(v["color_aov"], col)
+        # and against the oracle for one of them
+        pos, f, u, r = helpers.camera("D", w.dims, vxo)
+        p = vxo.make_params(W, H, pos, f, u, r, frame_number=7, shadow=1, bounce_samples=1)
+        views = [dict(fb=torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"), origin=pos, fwd=f, up=u, right=r,
+                      frame_number=7) for _ in range(2)]
+        ctx.RenderViews(W, H, views, vx.RenderOptions(shadow=True, bounce_samples=1))
+        want = w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"]
+        assert np.array_equal(views[0]["fb"].cpu().numpy(), want) and np.array_equal(views[1]["fb"].cpu().numpy(), want)
+        with pytest.raises(vx.VxrtError):
+            ctx.RenderViews(W, H, views * 9, vx.RenderOptions())   # 18 views: more than one launch takes
+    finally:
+        ctx.set_kernel_variant(default)
+        ctx.frame_stats()
+
+
 @pytest.mark.parametrize("gen,shape,factor", [(0, (128, 128, 128), 16), (2, (256, 256, 256), 32),
                                               (1, (128, 128, 128), 16), (2, (64, 64, 128), 8),
                                               (1, (512, 64, 64), 8)])

@@ -18,7 +18,7 @@ EXPORTS = [
     "vxrt_upload_world", "vxrt_build_world_procedural", "vxrt_world_info_get", "vxrt_download_world",
     "vxrt_save_world", "vxrt_load_world", "vxrt_world_file_info",
     "vxrt_set_environment", "vxrt_set_fov", "vxrt_set_ortho_window_size", "vxrt_get_directions",
-    "vxrt_render_flags_default", "vxrt_render", "vxrt_compact_rows", "vxrt_frame_stats_get",
+    "vxrt_render_flags_default", "vxrt_render", "vxrt_render_views", "vxrt_compact_rows", "vxrt_frame_stats_get",
     "vxrt_deinterleave_strips", "vxrt_trace_batch", "vxrt_trace_batch_host",
 ]
 
@@ -60,6 +60,13 @@ class RenderFlags(C.Structure):
         ("strip_rows", C.c_int32), ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("compact", C.c_int32),
         ("collect_stats", C.c_int32), ("tile_schedule", C.c_int32),
         ("d_color_aov", C.c_void_p), ("d_hit_aov", C.c_void_p), ("d_tile_order", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
+class View(C.Structure):
+    _fields_ = [
+        ("d_fb", C.c_void_p), ("origin", C.c_float * 3), ("fwd", C.c_float * 3), ("up", C.c_float * 3),
+        ("right", C.c_float * 3), ("frame_number", C.c_int64), ("d_color_aov", C.c_void_p), ("d_hit_aov", C.c_void_p),
     ]
 
 
@@ -109,6 +116,7 @@ def load() -> C.CDLL:
     L.vxrt_render_flags_default.argtypes = [C.POINTER(RenderFlags)]
     L.vxrt_render_flags_default.restype = None
     L.vxrt_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, f3, f3, f3, f3, C.POINTER(RenderFlags)]
+    L.vxrt_render_views.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(View), C.POINTER(RenderFlags)]
     L.vxrt_compact_rows.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32]
     L.vxrt_compact_rows.restype = C.c_uint32
     L.vxrt_frame_stats_get.argtypes = [C.c_void_p, C.POINTER(FrameStats)]

@@ -56,7 +56,12 @@ struct vxrt_ctx {
     int kernel_variant = 2;          // render: 2 = persistent waves (default), 0 = wave state machine, 1 = straightforward
     unsigned persistent_waves = 4096;
     unsigned long long* d_stats = nullptr;
+    unsigned launch_seq = 0;         // selects the tile counter of the next render launch
+    vxrt::ViewArgs* d_views = nullptr;  // per-view arguments of multi-view launches: a ring of slots
+    unsigned view_seq = 0;
 };
+constexpr unsigned kViewSlots = 16;  // multi-view launches that may be in flight at once on one context
+constexpr unsigned kTileCounterRing = 64;  // render launches that may be in flight at once on one context
 
 namespace vxrt {
 
@@ -142,10 +147,10 @@ int set_error(int code, const char* msg) { return fail(code, msg); }
 // still in flight when the queue runs dry is cheap.  The cost proxy needs the camera only: the elevation of the
 // centre ray of each 8-pixel tile row in a Y-up world -- rays just below the horizon travel farthest, rays
 // pointing up leave the grid at once.  A few hundred flops on the host per frame; scheduling only.
-static void schedule_tile_rows(RenderArgs& A)
+static void schedule_tile_rows(const RenderArgs& A, const f3& fwd, const f3& up, uint16_t* order, uint32_t& order_n)
 {
     const unsigned nty = (A.launch_rows + 7u) / 8u;
-    A.row_order_n = 0;
+    order_n = 0;
     if (nty < 2 || nty > kMaxScheduledTileRows)
         return;
     std::vector<std::pair<float, uint16_t>> key(nty);
@@ -158,10 +163,10 @@ static void schedule_tile_rows(RenderArgs& A)
             y = ((row / (unsigned)A.strip_rows) * (unsigned)A.strip_count + (unsigned)A.strip_index) * (unsigned)A.strip_rows +
                 row % (unsigned)A.strip_rows;
         const float sv = ((float)y / (float)A.height) * 2.0f - 1.0f;
-        float dy = A.fwd.y;
+        float dy = fwd.y;
         if (!A.ortho) {
-            const float dx = A.fwd.x + sv * A.ky * A.up.x, dz = A.fwd.z + sv * A.ky * A.up.z;
-            dy = A.fwd.y + sv * A.ky * A.up.y;
+            const float dx = fwd.x + sv * A.ky * up.x, dz = fwd.z + sv * A.ky * up.z;
+            dy = fwd.y + sv * A.ky * up.y;
             const float len = sqrtf(dx * dx + dy * dy + dz * dz);
             dy = len > 0.0f ? dy / len : dy;
         }
@@ -169,8 +174,8 @@ static void schedule_tile_rows(RenderArgs& A)
     }
     std::stable_sort(key.begin(), key.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
     for (unsigned j = 0; j < nty; ++j)
-        A.row_order[j] = key[j].second;
-    A.row_order_n = nty;
+        order[j] = key[j].second;
+    order_n = nty;
 }
 
 }  // namespace vxrt
@@ -195,10 +200,12 @@ int vxrt_create(int device, vxrt_ctx** out)
     if (!c)
         return fail(VXRT_ERR_NOMEM, "out of host memory");
     c->device = device;
-    // counters + one extra slot used as the persistent kernel's tile counter
-    hipError_t e = hipMalloc((void**)&c->d_stats, (vxrt::kStatCount + 1) * sizeof(unsigned long long));
+    // counters + a ring of tile counters for the persistent kernel: launches on different streams may be in flight
+    // together (frame k+1 fills the SIMD slots frame k's last waves leave), each needs its own queue head
+    const size_t stat_words = vxrt::kStatCount + kTileCounterRing / 2;
+    hipError_t e = hipMalloc((void**)&c->d_stats, stat_words * sizeof(unsigned long long));
     if (e == hipSuccess)
-        e = hipMemset(c->d_stats, 0, (vxrt::kStatCount + 1) * sizeof(unsigned long long));
+        e = hipMemset(c->d_stats, 0, stat_words * sizeof(unsigned long long));
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
@@ -223,6 +230,7 @@ int vxrt_destroy(vxrt_ctx* c)
     (void)hipDeviceSynchronize();
     vxrt::free_world(c);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_views) (void)hipFree(c->d_views);
     delete c;
     return VXRT_OK;
 }
@@ -416,11 +424,10 @@ uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_co
     return rows;
 }
 
-int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const float origin[3], const float fwd[3],
-                const float up[3], const float right[3], const vxrt_render_flags* fl)
+// one launch for `nviews` views; nviews == 0: the single view `views[0]` through the single-view kernel arguments
+static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned nviews, const vxrt_view* views,
+                         const vxrt_render_flags* fl)
 {
-    if (!c || !d_fb || !origin || !fwd || !up || !right)
-        return fail(VXRT_ERR_INVALID, "NULL argument");
     vxrt_render_flags def;
     if (!fl) {
         vxrt_render_flags_default(&def);
@@ -430,10 +437,14 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
         return fail(VXRT_ERR_INVALID, "vxrt_render_flags size mismatch");
     if (!c->has_world)
         return fail(VXRT_ERR_NO_WORLD, "no world resident");
-    if (width == 0 || height == 0)
-        return fail(VXRT_ERR_INVALID, "empty frame");
+    if (width == 0 || height == 0 || height > 65535u)
+        return fail(VXRT_ERR_INVALID, "empty frame, or more than 65535 rows");
     if (fl->strip_count > 1 && (fl->strip_rows <= 0 || fl->strip_index < 0 || fl->strip_index >= fl->strip_count))
         return fail(VXRT_ERR_INVALID, "bad strip sharding");
+    const unsigned n = nviews ? nviews : 1u;
+    for (unsigned v = 0; v < n; ++v)
+        if (!views[v].d_fb)
+            return fail(VXRT_ERR_INVALID, "a view has no framebuffer");
     VX_HIP(hipSetDevice(c->device));
     hipStream_t stream = (hipStream_t)fl->stream;
 
@@ -442,12 +453,6 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
     A.W = c->view;
     A.width = width;
     A.height = height;
-    if (fl->frame_number >= 0) {
-        A.frame_number = (uint32_t)fl->frame_number;
-    } else {
-        A.frame_number = c->frame_counter;  // the copy precedes the increment, Renderer.cu:310,322
-        c->frame_counter += 1;
-    }
     {   // getRayDirection's per-pixel constants (Renderer.cu:46,50-52), hoisted to the host
         float aspect = (float)width / (float)height;
         float fov = (float)((double)c->fov * 3.1415 / 180.0);
@@ -457,10 +462,6 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
         A.ortho_x = c->ortho[0];
         A.ortho_y = c->ortho[1];
     }
-    A.origin = vxrt::f3{origin[0], origin[1], origin[2]};
-    A.fwd = vxrt::f3{fwd[0], fwd[1], fwd[2]};
-    A.up = vxrt::f3{up[0], up[1], up[2]};
-    A.right = vxrt::f3{right[0], right[1], right[2]};
     A.light_dir = vxrt::f3{c->light_dir[0], c->light_dir[1], c->light_dir[2]};
     A.light_color = vxrt::f3{c->light_color[0], c->light_color[1], c->light_color[2]};
     A.ambient = vxrt::f3{c->ambient[0], c->ambient[1], c->ambient[2]};
@@ -487,18 +488,94 @@ int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const 
         A.launch_rows = vxrt_compact_rows(height, A.strip_rows, A.strip_count, A.strip_index);
     else
         A.launch_rows = height;
-    A.fb = (uint8_t*)d_fb;
-    A.color_aov = fl->d_color_aov;
-    A.hit_aov = (long long*)fl->d_hit_aov;
     A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
-    A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount);
     A.persistent_waves = c->persistent_waves;
-    A.tile_order = fl->d_tile_order;
-    if (fl->tile_schedule && !A.tile_order && c->kernel_variant == 2)
-        schedule_tile_rows(A);
+    const bool schedule = fl->tile_schedule && c->kernel_variant == 2;
+
+    auto frame_number_of = [&](const vxrt_view& v) -> uint32_t {
+        if (v.frame_number >= 0)
+            return (uint32_t)v.frame_number;
+        return c->frame_counter++;  // the copy precedes the increment, Renderer.cu:310,322
+    };
+    auto f3_of = [](const float* p) { return vxrt::f3{p[0], p[1], p[2]}; };
+
+    if (nviews == 0 || c->kernel_variant != 2) {  // single-view kernel arguments; variants 0/1 take the views one by one
+        for (unsigned v = 0; v < n; ++v) {
+            A.frame_number = frame_number_of(views[v]);
+            A.origin = f3_of(views[v].origin);
+            A.fwd = f3_of(views[v].fwd);
+            A.up = f3_of(views[v].up);
+            A.right = f3_of(views[v].right);
+            A.fb = (uint8_t*)views[v].d_fb;
+            A.color_aov = views[v].d_color_aov;
+            A.hit_aov = (long long*)views[v].d_hit_aov;
+            A.tile_order = nviews == 0 ? fl->d_tile_order : nullptr;
+            A.row_order_n = 0;
+            if (schedule && !A.tile_order)
+                vxrt::schedule_tile_rows(A, A.fwd, A.up, A.row_order, A.row_order_n);
+            A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
+            vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
+            VX_HIP(hipGetLastError());
+        }
+        return VXRT_OK;
+    }
+
+    // multi-view launch: the per-view arguments travel through a ring of device slots (stream-ordered copy)
+    if (!c->d_views)
+        VX_HIP(hipMalloc((void**)&c->d_views, sizeof(vxrt::ViewArgs) * vxrt::kMaxViews * kViewSlots));
+    std::vector<vxrt::ViewArgs> host(n);
+    for (unsigned v = 0; v < n; ++v) {
+        vxrt::ViewArgs& S = host[v];
+        memset(&S, 0, sizeof(S));
+        S.origin = f3_of(views[v].origin);
+        S.fwd = f3_of(views[v].fwd);
+        S.up = f3_of(views[v].up);
+        S.right = f3_of(views[v].right);
+        S.frame_number = frame_number_of(views[v]);
+        S.fb = (uint8_t*)views[v].d_fb;
+        S.color_aov = views[v].d_color_aov;
+        S.hit_aov = (long long*)views[v].d_hit_aov;
+        if (schedule)
+            vxrt::schedule_tile_rows(A, S.fwd, S.up, S.row_order, S.row_order_n);
+    }
+    vxrt::ViewArgs* slot = c->d_views + (size_t)(c->view_seq++ % kViewSlots) * vxrt::kMaxViews;
+    VX_HIP(hipMemcpyAsync(slot, host.data(), sizeof(vxrt::ViewArgs) * n, hipMemcpyHostToDevice, stream));
+    A.views = slot;
+    A.nviews = n;
+    A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
     vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
     VX_HIP(hipGetLastError());
     return VXRT_OK;
+}
+
+int vxrt_render(vxrt_ctx* c, uint32_t width, uint32_t height, void* d_fb, const float origin[3], const float fwd[3],
+                const float up[3], const float right[3], const vxrt_render_flags* fl)
+{
+    if (!c || !d_fb || !origin || !fwd || !up || !right)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    vxrt_view v;
+    memset(&v, 0, sizeof(v));
+    v.d_fb = d_fb;
+    for (int a = 0; a < 3; ++a) {
+        v.origin[a] = origin[a];
+        v.fwd[a] = fwd[a];
+        v.up[a] = up[a];
+        v.right[a] = right[a];
+    }
+    v.frame_number = fl ? fl->frame_number : -1;
+    v.d_color_aov = fl ? fl->d_color_aov : nullptr;
+    v.d_hit_aov = fl ? fl->d_hit_aov : nullptr;
+    return render_launch(c, width, height, 0, &v, fl);
+}
+
+int vxrt_render_views(vxrt_ctx* c, uint32_t width, uint32_t height, uint32_t n_views, const vxrt_view* views,
+                      const vxrt_render_flags* fl)
+{
+    if (!c || !views)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (n_views == 0 || n_views > vxrt::kMaxViews)
+        return fail(VXRT_ERR_INVALID, "between 1 and 16 views per launch");
+    return render_launch(c, width, height, n_views, views, fl);
 }
 
 int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)

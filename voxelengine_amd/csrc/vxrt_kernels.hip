@@ -45,20 +45,22 @@ __device__ __forceinline__ unsigned long long wave_sum(uint32_t v)
 struct PixelSink {
     const RenderArgs& A;
     int out_row;  // row inside the destination buffers (frame row, or packed shard row)
+    uint8_t* fb;  // the view's framebuffer and optional colour AOV
+    float* color_aov;
     __device__ void put(int x, int y, f3 c) const
     {
         if ((uint32_t)x >= A.width || (uint32_t)y >= A.height)
             return;
         size_t i = (size_t)out_row * A.width + (size_t)x;
-        if (A.color_aov) {
-            A.color_aov[i * 3 + 0] = c.x;
-            A.color_aov[i * 3 + 1] = c.y;
-            A.color_aov[i * 3 + 2] = c.z;
+        if (color_aov) {
+            color_aov[i * 3 + 0] = c.x;
+            color_aov[i * 3 + 1] = c.y;
+            color_aov[i * 3 + 2] = c.z;
         }
         // setPixelColor (Renderer.cu:72-87): clamp, *255, truncate; bytes b,g,r,a
         float r = lo(hi(c.x, 0), 1), g = lo(hi(c.y, 0), 1), b = lo(hi(c.z, 0), 1);
         uint32_t px = (uint32_t)(b * 255) | ((uint32_t)(g * 255) << 8) | ((uint32_t)(r * 255) << 16) | 0xFF000000u;
-        reinterpret_cast<uint32_t*>(A.fb)[i] = px;
+        reinterpret_cast<uint32_t*>(fb)[i] = px;
     }
 };
 
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A)
         if (A.compact && sharded)
             out_row = (int)((((uint32_t)y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
                             (uint32_t)y % (uint32_t)A.strip_rows);
-        PixelSink sink{A, out_row};
+        PixelSink sink{A, out_row, A.fb, A.color_aov};
 
         float u = (float)x / (float)Wd, v = (float)y / (float)Hd;
         f3 origin = A.origin;
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
     if (A.compact && sharded)
         out_row = (int)((((uint32_t)y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
                         (uint32_t)y % (uint32_t)A.strip_rows);
-    PixelSink sink{A, out_row};
+    PixelSink sink{A, out_row, A.fb, A.color_aov};
 
     // camera ray (getRayDirection / getRayDirectionOrtho, Renderer.cu:44-70)
     const float u = (float)x / (float)Wd, v = (float)y / (float)Hd;
@@ -548,18 +550,25 @@ void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t str
         return;
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
     if (variant == 2) {
-        const unsigned ntiles = ((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u);
-        const unsigned waves = ntiles < A.persistent_waves ? ntiles : A.persistent_waves;
+        const unsigned long long ntiles =
+            (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
+        const unsigned waves = ntiles < A.persistent_waves ? (unsigned)ntiles : A.persistent_waves;
         (void)hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
         const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
-        if (stats && second_bounce)
-            hipLaunchKernelGGL((k_render_persist<true, true>), dim3(waves), dim3(64), lds, stream, A);
-        else if (stats)
-            hipLaunchKernelGGL((k_render_persist<true, false>), dim3(waves), dim3(64), lds, stream, A);
-        else if (second_bounce)
-            hipLaunchKernelGGL((k_render_persist<false, true>), dim3(waves), dim3(64), lds, stream, A);
-        else
-            hipLaunchKernelGGL((k_render_persist<false, false>), dim3(waves), dim3(64), lds, stream, A);
+        const dim3 g(waves), b(64);
+#define VXRT_LAUNCH_PERSIST(S, B2, M) hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A)
+        if (A.nviews) {
+            if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, true);
+            else if (stats) VXRT_LAUNCH_PERSIST(true, false, true);
+            else if (second_bounce) VXRT_LAUNCH_PERSIST(false, true, true);
+            else VXRT_LAUNCH_PERSIST(false, false, true);
+        } else {
+            if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, false);
+            else if (stats) VXRT_LAUNCH_PERSIST(true, false, false);
+            else if (second_bounce) VXRT_LAUNCH_PERSIST(false, true, false);
+            else VXRT_LAUNCH_PERSIST(false, false, false);
+        }
+#undef VXRT_LAUNCH_PERSIST
         return;
     }
     if (variant == 1) {

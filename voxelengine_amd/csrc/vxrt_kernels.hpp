@@ -55,7 +55,23 @@ struct RenderArgs {
     // of tile rows, 0 = row-major).  Filled per frame by the host from the camera (vxrt_api.hip).
     unsigned int row_order_n;
     uint16_t row_order[kMaxScheduledTileRows];
+    // multi-view launch (vxrt_render_views): the per-view members above are unused, every view's live in `views`
+    // (device memory); the tile queue runs through view 0's tiles, then view 1's, ...
+    const struct ViewArgs* views;
+    unsigned int nviews;
 };
+
+// the per-view part of RenderArgs for a launch that renders several views of the same world
+struct ViewArgs {
+    f3 origin, fwd, up, right;
+    uint32_t frame_number;
+    uint32_t row_order_n;
+    uint8_t* fb;
+    float* color_aov;
+    long long* hit_aov;
+    uint16_t row_order[kMaxScheduledTileRows];
+};
+constexpr unsigned kMaxViews = 16;
 
 struct BatchArgs {
     WorldView W;

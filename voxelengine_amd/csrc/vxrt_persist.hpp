@@ -31,7 +31,7 @@ struct PixelCoords {
 };
 
 // launch (tx,row) -> pixel (Renderer.cu:183-196 + this build's strip sharding)
-__device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_t tx, uint32_t row)
+__device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_t frame_number, uint32_t tx, uint32_t row)
 {
     PixelCoords c;
     c.tx = tx;
@@ -56,7 +56,7 @@ __device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_
         c.y *= 2;
         if ((c.x % 2) == 0)
             c.y += 1;
-        if (A.frame_number % 2 == 0)
+        if (frame_number % 2 == 0)
             c.y += 1;
     }
     c.live = c.live && (uint32_t)c.x < A.width && (uint32_t)c.y < A.height;
@@ -70,19 +70,29 @@ __device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_
 }
 
 // getRayDirection / getRayDirectionOrtho (Renderer.cu:44-70)
-__device__ __forceinline__ void camera_ray(const RenderArgs& A, int x, int y, f3& origin, f3& ray)
+// the per-view inputs of one lane's pixel: kernel arguments for a single-view launch, loaded from the launch's
+// ViewArgs array for a multi-view one
+struct LaneView {
+    f3 origin, fwd, up, right;
+    uint32_t frame_number;
+    uint8_t* fb;
+    float* color_aov;
+    long long* hit_aov;
+};
+
+__device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& V, int x, int y, f3& origin, f3& ray)
 {
     const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
-    origin = A.origin;
+    origin = V.origin;
     if (A.ortho) {
-        ray = A.fwd;
-        origin = origin + ((A.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
-        origin = origin + (A.up * (v * 2 - 1)) * A.ortho_y;
+        ray = V.fwd;
+        origin = origin + ((V.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+        origin = origin + (V.up * (v * 2 - 1)) * A.ortho_y;
     } else {
         float su = u * 2 - 1, sv = v * 2 - 1;
-        ray.x = A.fwd.x + su * A.kx * A.right.x + sv * A.ky * A.up.x;
-        ray.y = A.fwd.y + su * A.kx * A.right.y + sv * A.ky * A.up.y;
-        ray.z = A.fwd.z + su * A.kx * A.right.z + sv * A.ky * A.up.z;
+        ray.x = V.fwd.x + su * A.kx * V.right.x + sv * A.ky * V.up.x;
+        ray.y = V.fwd.y + su * A.kx * V.right.y + sv * A.ky * V.up.y;
+        ray.z = V.fwd.z + su * A.kx * V.right.z + sv * A.ky * V.up.z;
         ray = unit3(ray);
     }
 }
@@ -92,12 +102,22 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, int x, int y, f3
 #endif
 // BOUNCE2: the second-bounce extension (bounce_depth 2) is compiled into its own instantiation -- carried as a
 // run-time branch it cost the reference ray set 29 more spilled VGPRs and 4 % of its speed.
-template <bool STATS, bool BOUNCE2>
+// MULTI: several views of the world in one launch (vxrt_render_views).  The queue runs through view 0's tiles, then
+// view 1's, ...: the next view's first tiles fill the lanes the previous view's last rays leave, so only the last
+// view of a launch pays the low-occupancy tail.  A lane keeps its pixel's view in the upper half of px_row.
+template <bool STATS, bool BOUNCE2, bool MULTI>
 __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderArgs A)
 {
     const WorldView& W = A.W;
     const int lane = threadIdx.x & 63;
     const unsigned long long lane_below = (1ull << lane) - 1ull;
+    auto lane_view = [&](uint32_t v) -> LaneView {
+        if (MULTI) {
+            const ViewArgs& S = A.views[v];
+            return LaneView{S.origin, S.fwd, S.up, S.right, S.frame_number, S.fb, S.color_aov, S.hit_aov};
+        }
+        return LaneView{A.origin, A.fwd, A.up, A.right, A.frame_number, A.fb, A.color_aov, A.hit_aov};
+    };
 
     WaveTracer<STATS> T;
     T.init(W);  // st = ST_DONE: every lane starts by asking for a pixel
@@ -115,7 +135,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
     // Whole tiles per ticket: one same-address atomic per 64 pixels.  A finer queue is limited by the atomic rate
     // (measured: 2x slower frames at 8 pixels per ticket), and handing out only the last tiles in smaller pieces
     // did not shorten the frame either.
-    uint32_t tile = 0, tile_used = 64u;
+    uint32_t tile = 0, tile_used = 64u, tile_view = 0;
     bool drained = false;
     unsigned long long dg_iters = 0, dg_walk = 0, dg_drain = 0;  // STATS only: loop diagnostics
     unsigned int dg_runs[3] = {0, 0, 0}, dg_lanes[3] = {0, 0, 0};  // next / end / box phase executions, lanes served
@@ -128,8 +148,9 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
     const f3 sray = unit3(L);
 
     // store one finished pixel (setPixelColor + the debug overlays of screenDispatch, Renderer.cu:213-275)
-    auto store_pixel = [&](const PixelCoords& pc, f3 origin, f3 ray, bool hit, f3 normal, f3 pos, f3 shaded) {
-        PixelSink sink{A, pc.out_row};
+    auto store_pixel = [&](const PixelCoords& pc, const LaneView& V, f3 origin, f3 ray, bool hit, f3 normal, f3 pos,
+                           f3 shaded) {
+        PixelSink sink{A, pc.out_row, V.fb, V.color_aov};
         const int Wd = (int)A.width, Hd = (int)A.height;
         if (hit) {
             if (A.mode == 1) {  // DEBUG_VIEW quadrants, Renderer.cu:215-243
@@ -189,9 +210,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             f3 l_origin = mk3(0, 0, 0), l_dir = mk3(1, 0, 0);
             int l_max = kMaxSteps;
             if (T.st == ST_DONE && stage != PX_NONE) {
-                const PixelCoords pc = pixel_coords(A, px_tx, px_row);
+                const LaneView V = lane_view(MULTI ? px_row >> 16 : 0u);
+                const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
                 f3 origin, ray;
-                camera_ray(A, pc.x, pc.y, origin, ray);
+                camera_ray(A, V, pc.x, pc.y, origin, ray);
                 TraceResult r;
                 T.result(W, r);
                 bool finalize = false, do_shade = false, shadowed = false, bounce = false, bounce2 = false;
@@ -199,8 +221,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     pcode = (r.hit && r.steps == 0) ? T.entry_code : T.out_code;
                     p_steps = r.steps;
                     position = r.pos;
-                    if (A.hit_aov)
-                        A.hit_aov[(size_t)pc.out_row * A.width + (size_t)pc.x] =
+                    if (V.hit_aov)
+                        V.hit_aov[(size_t)pc.out_row * A.width + (size_t)pc.x] =
                             r.hit ? (long long)r.vx + (long long)W.X * ((long long)r.vy + (long long)W.Y * (long long)r.vz) : -1ll;
                     n_hits += r.hit ? 1u : 0u;
                     color = mk3(0, 0, 0);
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 }
                 if (bounce || bounce2) {  // one sample of Renderer.cu:128-142, around the primary hit or the sample ray's
                     const uint32_t seed = pc.ty * A.width + pc.tx;
-                    const uint32_t si = seed + (uint32_t)sample * 1000u + (A.frame_number + 1u) * 1000u + (bounce2 ? 500u : 0u);
+                    const uint32_t si = seed + (uint32_t)sample * 1000u + (V.frame_number + 1u) * 1000u + (bounce2 ? 500u : 0u);
                     const f3 bn = mk3(bounce2 ? -r.normal.x : normal.x, bounce2 ? -r.normal.y : normal.y,
                                       bounce2 ? -r.normal.z : normal.z);
                     const f3 bo = mk3(bounce2 ? r.pos.x : position.x, bounce2 ? r.pos.y : position.y,
@@ -281,10 +303,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     stage = bounce2 ? PX_BOUNCE2 : PX_BOUNCE;
                 }
                 if (finalize) {
-                    store_pixel(pc, origin, ray, stage != PX_NONE, normal, position, color);
+                    store_pixel(pc, V, origin, ray, stage != PX_NONE, normal, position, color);
 #ifdef VXRT_TAIL_DEBUG  // development: when each pixel's chain started / ended (100 MHz ticks), and its primary steps
-                    if (STATS && A.color_aov) {
-                        float* o = A.color_aov + ((size_t)pc.out_row * A.width + (size_t)pc.x) * 3;
+                    if (STATS && V.color_aov) {
+                        float* o = V.color_aov + ((size_t)pc.out_row * A.width + (size_t)pc.x) * 3;
                         o[0] = (float)(px_t0 & 0xFFFFFFull);
                         o[1] = (float)(wall_clock64() & 0xFFFFFFull);
                         o[2] = (float)p_steps;
@@ -302,17 +324,24 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     if (lane == 0)
                         t = atomicAdd(A.tile_counter, 1u);
                     tile = (uint32_t)__shfl((int)t, 0, 64);
-                    if (tile >= ntiles) {
+                    if (tile >= ntiles * (MULTI ? A.nviews : 1u)) {
                         drained = true;
                         break;
                     }
                     tile_used = 0u;
                     // hand-out order: expected-longest ray chains first, so that what is still in flight when the
                     // queue runs dry is cheap (the host ranks the tile rows by the elevation of their centre ray)
-                    if (A.tile_order)
+                    if (MULTI) {
+                        tile_view = tile / ntiles;
+                        tile -= tile_view * ntiles;
+                        const ViewArgs& S = A.views[tile_view];
+                        if (S.row_order_n)
+                            tile = (uint32_t)S.row_order[tile / ntx] * ntx + tile % ntx;
+                    } else if (A.tile_order) {
                         tile = A.tile_order[tile];
-                    else if (A.row_order_n)
+                    } else if (A.row_order_n) {
                         tile = (uint32_t)A.row_order[tile / ntx] * ntx + tile % ntx;
+                    }
                 }
                 const uint32_t avail = 64u - tile_used;
                 const bool wants = ((want >> lane) & 1ull) != 0ull;
@@ -321,15 +350,18 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     const uint32_t p = tile_used + rank;
                     px_tx = (tile % ntx) * 8u + (p & 7u);
                     px_row = (tile / ntx) * 8u + (p >> 3);
-                    got = pixel_coords(A, px_tx, px_row).live;
+                    got = pixel_coords(A, MULTI ? A.views[tile_view].frame_number : A.frame_number, px_tx, px_row).live;
+                    if (MULTI)
+                        px_row |= tile_view << 16;
                 }
                 const uint32_t asked = (uint32_t)__popcll(want);
                 tile_used += asked < avail ? asked : avail;
                 want = __ballot(T.st == ST_DONE && stage == PX_NONE && !got);
             }
             if (got) {
-                const PixelCoords pc = pixel_coords(A, px_tx, px_row);
-                camera_ray(A, pc.x, pc.y, l_origin, l_dir);
+                const LaneView V = lane_view(MULTI ? px_row >> 16 : 0u);
+                const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
+                camera_ray(A, V, pc.x, pc.y, l_origin, l_dir);
                 l_max = kMaxSteps;
                 n_primary += 1;
                 launch = true;

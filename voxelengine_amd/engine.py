@@ -167,6 +167,14 @@ class Context:
                      color_aov=None, hit_aov=None, stream: int | None = None, tile_order=None) -> None:
         """Graphics::RenderScreen (VoxelRT/Renderer.cu:305-328).  ``d_fb``/AOVs: torch CUDA tensors or raw
         device addresses.  Asynchronous on ``stream`` (default: torch's current stream)."""
+        fl = self._flags(opts, stream)
+        fl.d_color_aov = _ptr(color_aov)
+        fl.d_hit_aov = _ptr(hit_aov)
+        fl.d_tile_order = _ptr(tile_order)
+        N.check(self._L.vxrt_render(self._h, width, height, _ptr(d_fb), _f3(origin), _f3(fwd), _f3(up), _f3(right),
+                                    C.byref(fl)))
+
+    def _flags(self, opts: RenderOptions | None, stream: int | None) -> "N.RenderFlags":
         o = opts or RenderOptions()
         fl = N.RenderFlags()
         self._L.vxrt_render_flags_default(C.byref(fl))
@@ -177,12 +185,24 @@ class Context:
         fl.compact, fl.collect_stats = int(o.compact), int(o.collect_stats)
         fl.tile_schedule = int(o.tile_schedule)
         fl.bounce_depth = int(o.bounce_depth)
-        fl.d_color_aov = _ptr(color_aov)
-        fl.d_hit_aov = _ptr(hit_aov)
-        fl.d_tile_order = _ptr(tile_order)
         fl.stream = _stream(stream)
-        N.check(self._L.vxrt_render(self._h, width, height, _ptr(d_fb), _f3(origin), _f3(fwd), _f3(up), _f3(right),
-                                    C.byref(fl)))
+        return fl
+
+    def RenderViews(self, width: int, height: int, views, opts: RenderOptions | None = None,
+                    stream: int | None = None) -> None:
+        """Several views of the resident world in ONE launch (vxrt_render_views): the next view's first tiles fill
+        the lanes the previous view's last rays leave.  ``views``: sequence of dicts with keys ``fb, origin, fwd, up,
+        right`` and optionally ``frame_number`` (default: ``opts.frame_number``, or the context counter), ``color_aov``,
+        ``hit_aov``.  Every view equals what :meth:`RenderScreen` produces for it."""
+        fl = self._flags(opts, stream)
+        arr = (N.View * len(views))()
+        for dst, v in zip(arr, views):
+            dst.d_fb = _ptr(v["fb"])
+            dst.origin, dst.fwd, dst.up, dst.right = _f3(v["origin"]), _f3(v["fwd"]), _f3(v["up"]), _f3(v["right"])
+            dst.frame_number = int(v.get("frame_number", fl.frame_number))
+            dst.d_color_aov = _ptr(v.get("color_aov"))
+            dst.d_hit_aov = _ptr(v.get("hit_aov"))
+        N.check(self._L.vxrt_render_views(self._h, width, height, len(views), arr, C.byref(fl)))
 
     def frame_stats(self) -> "N.FrameStats":
         st = N.FrameStats()
