@@ -4,12 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one 1920x1080 frame of BASELINE.json configs[2]: primary ray + shadow ray for every primary hit +
-1 bounce sample (reference gate `lDot == 0`), 8192x512x8192 procedurally generated brickmap (factor 32), the
-four fixed cameras used round-robin.  With N > 1 the frame is sharded by interleaved 16-row strips, the
-brickmap is replicated per GPU and the packed strips are gathered to rank 0 over RCCL (strong scaling: the
-frame is fixed).  `value` = rays actually traced by all ranks / wall time of the K timed steps (inputs resident
-in HBM, gather included).  Rank 0 prints ONE JSON line.
+One step = one launch over the four benchmark views (cameras A-D), each a 1920x1080 frame of BASELINE.json
+configs[2]: primary ray + shadow ray for every primary hit + 1 bounce sample (reference gate `lDot == 0`),
+8192x512x8192 procedurally generated brickmap (factor 32).  `--views-per-step 1` gives the reference's one view per
+launch.  With N > 1 every view is sharded by interleaved 16-row strips, the brickmap is replicated per GPU and the
+packed strips of the step are gathered to rank 0 over RCCL in one collective (strong scaling: the frames are fixed).
+`value` = rays actually traced by all ranks / wall time of the K timed steps (inputs resident in HBM, gather
+included).  Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
 
@@ -58,6 +59,8 @@ def parse():
     ap.add_argument("--workload", default="c3_8k_1080p_shadow_bounce", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
+    ap.add_argument("--views-per-step", type=int, default=4,
+                    help="views rendered by one launch (vxrt_render_views); 1 = one RenderScreen-style launch per frame")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
     ap.add_argument("--bounce-depth", type=int, default=1, help="2 = second bounce (BASELINE config 5; extension beyond the reference)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -110,37 +113,55 @@ def main():
         f, u, r = vx.GetDirections(euler)
         cams.append((name, (frac[0] * X, frac[1] * Y, frac[2] * Z), f, u, r))
 
+    # One step = one launch over V views (the benchmark cameras in turn; frame g of the run uses camera g mod 4 and
+    # FrameNumber g + 1).  V = 1 is the reference's one-view-per-RenderScreen behaviour.
+    V = max(1, min(16, args.views_per_step))
     plan = sharding.ShardPlan(W, H, sharding.STRIP_ROWS, world, rank)
-    local = torch.zeros(plan.shard_bytes, dtype=torch.uint8, device=dev)
-    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    shards = torch.zeros((world, plan.shard_bytes), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
+    step_bytes = V * plan.shard_bytes  # what a rank contributes per step when sharded: V packed shards back to back
+    local = torch.zeros(step_bytes, dtype=torch.uint8, device=dev)
+    frames = torch.zeros((V, H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    shards = torch.zeros((world, step_bytes), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
 
-    def opts(frame_number, stats=False):
+    def opts(stats=False):
         return vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, bounce_all_hits=bool(args.bounce_all_hits),
-                                bounce_depth=args.bounce_depth, frame_number=frame_number, strip_rows=plan.strip_rows, strip_count=world,
+                                bounce_depth=args.bounce_depth, strip_rows=plan.strip_rows, strip_count=world,
                                 strip_index=rank, compact=world > 1, collect_stats=stats)
 
-    def deinterleave(sh, fr):
-        ctx.deinterleave_strips(W, H, plan.strip_rows, world, sh, plan.shard_bytes, fr)
+    def views_of(i, target, hits=None):
+        """the V views of step i, rendered into `target` ((V,H,W,4) frames, or V packed shards back to back)"""
+        out = []
+        for j in range(V):
+            g = i * V + j
+            name, pos, f, u, r = cams[g % len(cams)]
+            fb = target[j] if target.dim() == 4 else target[j * plan.shard_bytes:(j + 1) * plan.shard_bytes]
+            v = dict(fb=fb, origin=pos, fwd=f, up=u, right=r, frame_number=g + 1)
+            if hits is not None:
+                v["hit_aov"] = hits[j]
+            out.append(v)
+        return out
 
-    # N > 1: two-deep pipeline, the RCCL gather of frame k overlaps the render of frame k+1
+    def deinterleave(sh, fr):
+        for j in range(V):  # shards of view j sit at byte offset j * shard_bytes of every rank's contribution
+            ctx.deinterleave_strips(W, H, plan.strip_rows, world, sh.data_ptr() + j * plan.shard_bytes, step_bytes, fr[j])
+
+    # N > 1: two-deep pipeline, the RCCL gather of step k overlaps the render of step k+1
     pipe = None
     if world > 1 and not rehearse:
-        pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frame, deinterleave)
+        pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames, deinterleave,
+                                       nbytes=step_bytes)
 
     def step(i, ev=None):
-        name, pos, f, u, r = cams[i % len(cams)]
-        target = frame if world == 1 else (pipe.local(i) if pipe else local)
+        target = frames if world == 1 else (pipe.local(i) if pipe else local)
         if ev is not None:
             ev[0].record()
-        ctx.RenderScreen(W, H, target, pos, f, u, r, opts(i + 1))
+        ctx.RenderViews(W, H, views_of(i, target), opts())
         if ev is not None:
             ev[1].record()
         if pipe:
             pipe.submit(i)
         elif world > 1:
-            host = torch.zeros((world, plan.shard_bytes), dtype=torch.uint8) if rank == 0 else None
-            sharding.gather_frame(plan, local.cpu(), host, frame,
+            host = torch.zeros((world, step_bytes), dtype=torch.uint8) if rank == 0 else None
+            sharding.gather_frame(plan, local.cpu(), host, frames,
                                   lambda sh, fr: (shards.copy_(sh), deinterleave(shards, fr)))
 
     def fence():
@@ -167,9 +188,7 @@ def main():
 
     # algorithmic bytes of the same K launches, from the probe-counting kernel variant, untimed
     for k in range(args.steps):
-        i = args.warmup + k
-        name, pos, f, u, r = cams[i % len(cams)]
-        ctx.RenderScreen(W, H, frame if world == 1 else local, pos, f, u, r, opts(i + 1, stats=True))  # `local`: scratch
+        ctx.RenderViews(W, H, views_of(args.warmup + k, frames if world == 1 else local), opts(stats=True))  # `local`: scratch
     sp = ctx.frame_stats()
     assert sp.total_rays() == rays_local, "ray counts differ between the timed and the counting pass"
     bytes_local = sp.algorithmic_bytes()
@@ -208,6 +227,9 @@ def main():
                 "rays": "primary + shadow per hit + %d bounce sample(s), gate=%s%s" % (
                     bounce, "all-hits" if args.bounce_all_hits else "reference lDot==0",
                     ", second bounce (extension beyond the reference)" if args.bounce_depth >= 2 else ""),
+                "step": "one launch over %d view(s) of %dx%d: cameras %s in turn" % (
+                    V, W, H, ",".join(c[0] for c in CAMERAS)),
+                "views_per_step": V,
                 "cameras": [c[0] for c in CAMERAS], "sharding": "interleaved %d-row strips, gather to rank 0" % plan.strip_rows
                 if world > 1 else "none", "rays_per_step": round(rays_total / args.steps, 1),
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
@@ -218,19 +240,19 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
                          "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1)},
         }
-        if rehearse:  # the gathered frame of the last step must equal a single-GPU render of the same frame
-            i = args.warmup + args.steps - 1
-            name, pos, f, u, r = cams[i % len(cams)]
-            full = torch.zeros_like(frame)
-            ctx.RenderScreen(W, H, full, pos, f, u, r, vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,
-                                                                   bounce_all_hits=bool(args.bounce_all_hits),
-                                                                   bounce_depth=args.bounce_depth, frame_number=i + 1))
+        if rehearse:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
+            full = torch.zeros_like(frames)
+            for v in views_of(args.warmup + args.steps - 1, full):
+                ctx.RenderScreen(W, H, v["fb"], v["origin"], v["fwd"], v["up"], v["right"],
+                                 vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,
+                                                  bounce_all_hits=bool(args.bounce_all_hits), bounce_depth=args.bounce_depth,
+                                                  frame_number=v["frame_number"]))
             torch.cuda.synchronize()
-            result["rehearsal"] = {"gathered_frame_equals_single_gpu_frame": bool(torch.equal(full, frame)),
+            result["rehearsal"] = {"gathered_frame_equals_single_gpu_frame": bool(torch.equal(full, frames)),
                                    "note": "all ranks on one GPU over gloo: value is not a measurement"}
             ctx.frame_stats()
         if args.cpu_baseline == "auto" and world == 1:
-            result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts)
+            result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -250,10 +272,11 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts):
+def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts):
     """The CPU oracle (kind "port": this repo's C restatement of the reference algorithm) timed on the GPU box's
-    host cores on a bounded sample of the same workload: `--cpu-frames` full frames.  The same frames double as a
-    parity gate: the HIP framebuffer must equal the oracle's byte for byte."""
+    host cores on a bounded sample of the same workload: the frames of `--cpu-frames / V` steps.  The same frames double
+    as a parity gate: the HIP framebuffers of the same steps (same launches as the timed ones) must equal the oracle's
+    byte for byte, and so must the primary hit voxel indices."""
     import torch
     from oracle import vxo
 
@@ -264,27 +287,28 @@ def cpu_baseline(ctx, vx, cams, W, H, shadow, bounce, args, frame, opts):
     secs = 0.0
     mismatched = 0
     hit_mismatch = 0
-    names = []
-    for n in range(args.cpu_frames):
-        i = args.warmup + n
-        name, pos, f, u, r = cams[i % len(cams)]
-        names.append(name)
-        p = vxo.make_params(W, H, pos, f, u, r, frame_number=i + 1, shadow=shadow, bounce_samples=bounce,
-                            bounce_all_hits=args.bounce_all_hits, bounce_depth=args.bounce_depth)
-        t0 = time.perf_counter()
-        out = world.render(p, fb=np.zeros((H, W, 4), np.uint8), want_hit=True, nthreads=cores)
-        secs += time.perf_counter() - t0
-        rays += out["stats"].total_rays()
-        frame.zero_()
-        hit = torch.full((H, W), -1, dtype=torch.int64, device=frame.device)
-        ctx.RenderScreen(W, H, frame, pos, f, u, r, opts(i + 1), hit_aov=hit)
-        mismatched += int((frame.cpu().numpy() != out["fb"]).any(axis=2).sum())
-        hit_mismatch += int((hit.cpu().numpy() != out["hit"]).sum())
+    nframes = 0
+    for s in range(max(1, args.cpu_frames // V)):
+        frames.zero_()
+        hits = torch.full((V, H, W), -1, dtype=torch.int64, device=frames.device)
+        views = views_of(args.warmup + s, frames, hits)
+        ctx.RenderViews(W, H, views, opts())
+        gpu_fb, gpu_hit = frames.cpu().numpy(), hits.cpu().numpy()
+        for j, v in enumerate(views):
+            p = vxo.make_params(W, H, v["origin"], v["fwd"], v["up"], v["right"], frame_number=v["frame_number"], shadow=shadow,
+                                bounce_samples=bounce, bounce_all_hits=args.bounce_all_hits, bounce_depth=args.bounce_depth)
+            t0 = time.perf_counter()
+            out = world.render(p, fb=np.zeros((H, W, 4), np.uint8), want_hit=True, nthreads=cores)
+            secs += time.perf_counter() - t0
+            rays += out["stats"].total_rays()
+            nframes += 1
+            mismatched += int((gpu_fb[j] != out["fb"]).any(axis=2).sum())
+            hit_mismatch += int((gpu_hit[j] != out["hit"]).sum())
     ctx.frame_stats()
     base = {"value": round(rays / secs / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d full %dx%d frame(s) of the same workload (cameras %s), %.1f s of CPU work" % (
-                args.cpu_frames, W, H, ",".join(names), secs)}
-    parity = {"frames": args.cpu_frames, "pixels_differing": mismatched, "hit_voxel_indices_differing": hit_mismatch,
+            "sample": "%d full %dx%d frame(s) of the same workload (the frames of %d step(s)), %.1f s of CPU work" % (
+                nframes, W, H, nframes // V, secs)}
+    parity = {"frames": nframes, "pixels_differing": mismatched, "hit_voxel_indices_differing": hit_mismatch,
               "oracle": "cpu restatement (parity with the reference itself: unpinned)"}
     return base, parity
 

@@ -64,10 +64,13 @@ class GatherPipeline:
     (``work.wait()`` orders the stream, it does not block the host for NCCL).
     """
 
-    def __init__(self, plan: ShardPlan, make_buffer, frame_on_root, deinterleave, group=None):
+    def __init__(self, plan: ShardPlan, make_buffer, frame_on_root, deinterleave, group=None, nbytes: int | None = None):
+        """``nbytes``: bytes each rank contributes per step (default one packed shard; several views per launch
+        contribute several shards back to back -- one larger collective instead of several small ones)."""
         self.plan, self.frame, self.deinterleave, self.group = plan, frame_on_root, deinterleave, group
-        self.locals = [make_buffer(plan.shard_bytes) for _ in range(2)]
-        self.shards = [make_buffer(plan.world_size * plan.shard_bytes).view(plan.world_size, plan.shard_bytes)
+        nbytes = plan.shard_bytes if nbytes is None else int(nbytes)
+        self.locals = [make_buffer(nbytes) for _ in range(2)]
+        self.shards = [make_buffer(plan.world_size * nbytes).view(plan.world_size, nbytes)
                        for _ in range(2)] if plan.rank == 0 else [None, None]
         self.works = [None, None]
         self.pending = None  # frame index gathered but not yet de-interleaved on the root
