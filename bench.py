@@ -213,7 +213,8 @@ def main():
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                traffic = json.load(open(tj)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                key = {4: args.workload, 1: args.workload + "_single_view_launch"}.get(V)  # profiled launch shapes
+                traffic = json.load(open(tj)).get(key, {}).get("hbm_bytes_per_launch") if world == 1 else None
             except Exception:
                 traffic = None
         result = {
