@@ -84,8 +84,22 @@ while time.time() < t_end:
         if not np.array_equal(d_hit.cpu().numpy(), want["hit"]):
             fail("hit indices variant %d" % variant, seed, "cam %s %dx%d %r" % (cam, W, H, kw))
     ctx.set_kernel_variant(2)
+    # the same configuration as a multi-view launch: this view plus two others, each against its own oracle frame
+    views, wants = [], []
+    for j in range(3):
+        cj = cam if j == 0 else str(rng.choice(["A", "B", "C", "D"]))
+        pj, fj, uj, rj = helpers.camera(cj, w.dims, vxo)
+        kwj = dict(kw, frame_number=kw["frame_number"] + j)
+        wants.append(want["fb"] if j == 0 else w.render(vxo.make_params(W, H, pj, fj, uj, rj, ortho_size=(size, size), **kwj),
+                                                         fb=fb0.copy())["fb"])
+        views.append(dict(fb=torch.from_numpy(fb0.copy()).cuda(), origin=pj, fwd=fj, up=uj, right=rj,
+                          frame_number=kwj["frame_number"]))
+    ctx.RenderViews(W, H, views, opts)
+    for j in range(3):
+        if not np.array_equal(views[j]["fb"].cpu().numpy(), wants[j]):
+            fail("multi-view launch, view %d" % j, seed, "cam %s %dx%d %r" % (cam, W, H, kw))
     ctx.frame_stats()
-    frames_checked += 3
+    frames_checked += 6
     rounds += 1
     if rounds % 10 == 0:
         print("round %d (seed %d): %d rays, %d frames checked, all equal" % (rounds, seed, rays_checked, frames_checked), flush=True)
