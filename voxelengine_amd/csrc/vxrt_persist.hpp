@@ -69,7 +69,6 @@ __device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_
     return c;
 }
 
-// getRayDirection / getRayDirectionOrtho (Renderer.cu:44-70)
 // the per-view inputs of one lane's pixel: kernel arguments for a single-view launch, loaded from the launch's
 // ViewArgs array for a multi-view one
 struct LaneView {
@@ -80,6 +79,7 @@ struct LaneView {
     long long* hit_aov;
 };
 
+// getRayDirection / getRayDirectionOrtho (Renderer.cu:44-70)
 __device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& V, int x, int y, f3& origin, f3& ray)
 {
     const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
     int p_steps = 0;
     float occl = 0.0f;
     int sample = 0;
-    uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
+    uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;  // wave-uniform (ballot counts): scalar registers
 
     // the wave's share of the tile queue (wave-uniform)
     const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
         // expensive part of this phase).
         if (vote_run(n_next, n_walk + n_box + n_end, VXRT_VOTE_NEXT)) {
             bool launch = false;
+            bool c_hit = false, c_shadow = false, c_bounce = false;  // this lane's contribution to the ray counters
             f3 l_origin = mk3(0, 0, 0), l_dir = mk3(1, 0, 0);
             int l_max = kMaxSteps;
             if (T.st == ST_DONE && stage != PX_NONE) {
@@ -224,13 +225,13 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     if (V.hit_aov)
                         V.hit_aov[(size_t)pc.out_row * A.width + (size_t)pc.x] =
                             r.hit ? (long long)r.vx + (long long)W.X * ((long long)r.vy + (long long)W.Y * (long long)r.vz) : -1ll;
-                    n_hits += r.hit ? 1u : 0u;
+                    c_hit = r.hit;
                     color = mk3(0, 0, 0);
                     if (!(r.hit && A.mode == 0)) {
                         stage = r.hit ? PX_PRIMARY : PX_NONE;  // remember hit/miss for the store below
                         finalize = true;
                     } else if (A.shadow) {
-                        n_shadow += 1;
+                        c_shadow = true;
                         launch = true;  // Renderer.cu:97-102
                         l_origin = position + sray * 0.01f;
                         l_dir = sray;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     sd = unit3(sd);
                     if (dot3(sd, bn) < 0)
                         sd = reflect3(sd, bn);
-                    n_bounce += 1;
+                    c_bounce = true;
                     launch = true;
                     l_origin = bo + bn * 0.01f;
                     l_dir = sd;
@@ -363,7 +364,6 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
                 camera_ray(A, V, pc.x, pc.y, l_origin, l_dir);
                 l_max = kMaxSteps;
-                n_primary += 1;
                 launch = true;
                 stage = PX_PRIMARY;
 #ifdef VXRT_TAIL_DEBUG
@@ -374,6 +374,11 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 T.begin_ray(W, l_origin, l_dir, l_max);
             if (drained && T.st == ST_DONE && stage == PX_NONE)
                 T.st = ST_IDLE;
+            // ray counters: ballots here, where the whole wave is converged again
+            n_primary += (uint32_t)__popcll(__ballot(got));
+            n_shadow += (uint32_t)__popcll(__ballot(c_shadow));
+            n_bounce += (uint32_t)__popcll(__ballot(c_bounce));
+            n_hits += (uint32_t)__popcll(__ballot(c_hit));
         }
 
         if (vote_run(n_end, n_walk + n_box, VXRT_VOTE_END)) {
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
         T.step(W);
     }
 
-    unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_bounce), s3 = wave_sum(n_hits);
+    const unsigned long long s0 = n_primary, s1 = n_shadow, s2 = n_bounce, s3 = n_hits;
     if (lane == 0 && A.stats) {
         atomicAdd(&A.stats[kStatPrimary], s0);
         atomicAdd(&A.stats[kStatShadow], s1);
