@@ -84,6 +84,49 @@ def _pipeline_worker(rank, world, port, W, H, rows, out_path):
     dist.destroy_process_group()
 
 
+def _multi_view_pipeline_worker(rank, world, port, W, H, rows, views, out_path):
+    """bench.py's N > 1 step: `views` packed shards back to back per rank, one gather per step."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plan = sharding.ShardPlan(W, H, rows, world, rank)
+    sb = plan.shard_bytes
+    frames_out = torch.zeros((views, H, W, 4), dtype=torch.uint8) if rank == 0 else None
+    seen = []
+
+    def deint(shards, fr):   # shards: (world, views * shard_bytes); view j of rank r at bytes [j*sb, (j+1)*sb)
+        for j in range(views):
+            _reference_deinterleave(plan)(shards[:, j * sb:(j + 1) * sb].contiguous(), fr[j])
+        seen.append(fr.clone())
+
+    pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8), frames_out, deint, nbytes=views * sb)
+    steps = []
+    for k in range(4):
+        g = torch.Generator().manual_seed(500 + k)
+        full = torch.randint(0, 256, (views, H, W, 4), dtype=torch.uint8, generator=g)
+        steps.append(full)
+        buf = pipe.local(k)
+        assert buf.numel() == views * sb
+        for j in range(views):
+            bj = buf[j * sb:(j + 1) * sb].view(plan.max_rows, W, 4)
+            for lr in range(plan.local_rows):
+                bj[lr] = full[j, plan.frame_row(rank, lr)]
+        pipe.submit(k)
+    pipe.flush()
+    if rank == 0:
+        ok = len(seen) == 4 and all(torch.equal(a, b) for a, b in zip(seen, steps))
+        torch.save(dict(ok=bool(ok)), out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,views", [(2, 4), (3, 2)])
+def test_gather_pipeline_with_several_views_per_step_gloo(tmp_path, world, views):
+    out_path = str(tmp_path / "res.pt")
+    mp.spawn(_multi_view_pipeline_worker, args=(world, _free_port(), 32, 40, 8, views, out_path), nprocs=world, join=True)
+    assert torch.load(out_path)["ok"]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_deep_gather_pipeline_gloo(tmp_path, world):
     """GatherPipeline: frame k's gather overlaps frame k+1's render; buffers are reused only after their
