@@ -4,11 +4,12 @@
 // is a scripted path instead of keyboard/mouse input; the last frame is written as raw BGRA and as a PPM.
 //
 //   voxelapp_headless [world_edge=256] [frames=2] [out_prefix=frame] [width=320] [height=180] [shaded=0]
-//                     [camera_path_file] [dump_every_frame=0]
+//                     [camera_path_file] [dump_every_frame=0] [views_per_launch=1]
 //
 // camera_path_file replaces the fixed camera: one frame per line, "x y z eulerX eulerY eulerZ" (voxels, radians;
 // '#' starts a comment); `frames` is then the number of lines.  With dump_every_frame=1 each frame is also written
 // as <out_prefix>_NNNN.ppm (under checkerboard rendering a frame keeps the other half of the previous one).
+// views_per_launch > 1 renders that many poses per launch through Graphics::RenderScreens (no checkerboard then).
 #include "../include/GPUDDA/Renderer.h"
 #include "../include/GPUDDA/VoxelWorldBuilder.h"
 
@@ -35,6 +36,7 @@ int main(int argc, char** argv)
     const bool shaded = argc > 6 && atoi(argv[6]) != 0;
     const std::string path_file = argc > 7 ? argv[7] : "";
     const bool dump_all = argc > 8 && atoi(argv[8]) != 0;
+    const int batch = argc > 9 ? atoi(argv[9]) : 1;
 
     struct Pose {
         float3 pos, euler;
@@ -119,7 +121,48 @@ int main(int argc, char** argv)
 
     double avgFrameTime = 0.0;
     const int nframes = path.empty() ? frames : (int)path.size();
-    for (int i = 0; i < nframes; ++i) {
+    if (batch > 1) {
+        // several poses per launch (Graphics::RenderScreens): every view has its own framebuffer, so this mode runs
+        // without the checkerboard's frame-to-frame history
+        RenderSwitches s;
+        s.DebugView = !shaded;
+        s.Checkerboard = false;
+        s.ShadowRay = shaded;
+        s.BounceSamples = shaded ? 1 : 0;
+        SetRenderSwitches(s);
+        std::vector<void*> d_views((size_t)batch, nullptr);
+        for (auto& p : d_views)
+            if (hipMalloc(&p, (size_t)width * height * sizeof(BGRA8888)) != hipSuccess)
+                return 1;
+        for (int first = 0; first < nframes; first += batch) {
+            const int n = nframes - first < batch ? nframes - first : batch;
+            std::vector<ScreenView> views((size_t)n);
+            auto f0 = std::chrono::high_resolution_clock::now();
+            for (int j = 0; j < n; ++j) {
+                if (!path.empty()) {
+                    cam_pos = path[(size_t)(first + j)].pos;
+                    cam_eular = path[(size_t)(first + j)].euler;
+                }
+                GetDirections(cam_eular, &cam_forward, &cam_up, &cam_right);
+                views[(size_t)j] = ScreenView{d_views[(size_t)j], cam_pos, cam_forward, cam_up, cam_right};
+            }
+            RenderScreens(raytracer, width, height, views.data(), (uint32_t)n);
+            auto f1 = std::chrono::high_resolution_clock::now();
+            double td = std::chrono::duration_cast<std::chrono::microseconds>(f1 - f0).count() / 1000.0 / n;
+            avgFrameTime = first == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
+            for (int j = 0; j < n; ++j) {
+                (void)hipMemcpy(pixels.data(), d_views[(size_t)j], pixels.size() * sizeof(BGRA8888), hipMemcpyDeviceToHost);
+                if (dump_all) {
+                    char name[32];
+                    std::snprintf(name, sizeof(name), "_%04d.ppm", first + j);
+                    write_ppm(prefix + name);
+                }
+            }
+        }
+        for (auto p : d_views)
+            (void)hipFree(p);
+    }
+    for (int i = 0; batch <= 1 && i < nframes; ++i) {
         if (!path.empty()) {
             cam_pos = path[(size_t)i].pos;
             cam_eular = path[(size_t)i].euler;

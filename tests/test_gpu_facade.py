@@ -71,3 +71,29 @@ def test_headless_voxelapp_replays_a_camera_path(vxo, tmp_path):
     bad = subprocess.run([EXE, str(edge), "0", prefix, str(W), str(H), "1", str(tmp_path / "none.txt")],
                          capture_output=True, text=True, timeout=300)
     assert bad.returncode == 2
+
+
+@pytest.mark.gpu
+def test_headless_voxelapp_renders_several_poses_per_launch(vxo, tmp_path):
+    """Graphics::RenderScreens (this build's addition to the reference-shaped API): the camera path rendered two
+    poses per launch; every dumped frame equals the oracle's frame for that pose and FrameNumber."""
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    W, H, edge = 160, 96, 256
+    poses = [((64.0, 230.0, 64.0), (-0.45, 0.7, 0.0)), ((70.5, 228.0, 66.0), (-0.5, 0.8, 0.0)),
+             ((80.0, 220.25, 72.0), (-0.6, 1.0, 0.0))]
+    path = tmp_path / "path.txt"
+    path.write_text("".join("%r %r %r %r %r %r\n" % (*p, *e) for p, e in poses))
+    prefix = str(tmp_path / "multi")
+    out = subprocess.run([EXE, str(edge), "0", prefix, str(W), str(H), "1", str(path), "1", "2"], capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    w = vxo.World.generate(vxo.GEN_PERLIN_REF, edge, edge, edge, 32, nthreads=16)
+    for frame, (pos, euler) in enumerate(poses):
+        f, u, r = vxo.get_directions(euler)
+        p = vxo.make_params(W, H, tuple(np.float32(v) for v in pos), f, u, r, frame_number=frame, mode=vxo.MODE_SHADED,
+                            shadow=1, bounce_samples=1)
+        want = w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"]
+        raw = open("%s_%04d.ppm" % (prefix, frame), "rb").read()
+        head = b"P6\n%d %d\n255\n" % (W, H)
+        rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
+        assert np.array_equal(rgb, want[:, :, [2, 1, 0]]), frame

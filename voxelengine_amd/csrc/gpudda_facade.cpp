@@ -316,8 +316,8 @@ void SetFOV(float fov) { g_fov = fov; }
 void SetOrthoWindowSize(float2 s) { g_ortho = s; }
 void SetRenderSwitches(const RenderSwitches& s) { g_switches = s; }
 
-void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_texture, float3 origin, float3 fwd, float3 up,
-                  float3 right)
+// globals -> context state and launch flags (what RenderScreen copies to dFrameInfo / reads from g_env)
+static vxrt_ctx* prepare_launch(VoxelRaytracer3D* rt, vxrt_render_flags& fl)
 {
     vxrt_ctx* c = rt->Context();
     const float L[3] = {g_env.LightDirection.x, g_env.LightDirection.y, g_env.LightDirection.z};
@@ -326,7 +326,6 @@ void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_t
     ok(vxrt_set_environment(c, L, C, A), "vxrt_set_environment");
     ok(vxrt_set_fov(c, g_fov), "vxrt_set_fov");
     ok(vxrt_set_ortho_window_size(c, g_ortho.x, g_ortho.y), "vxrt_set_ortho_window_size");
-    vxrt_render_flags fl;
     vxrt_render_flags_default(&fl);
     fl.mode = g_switches.DebugView ? VXRT_MODE_DEBUG : VXRT_MODE_SHADED;
     fl.checkerboard = g_switches.Checkerboard;
@@ -336,10 +335,42 @@ void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_t
     fl.bounce_all_hits = g_switches.BounceAllHits;
     fl.bounce_depth = g_switches.BounceDepth;
     fl.frame_number = -1;  // the context's counter: copy, then increment (Renderer.cu:310,322)
+    return c;
+}
+
+void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_texture, float3 origin, float3 fwd, float3 up,
+                  float3 right)
+{
+    vxrt_render_flags fl;
+    vxrt_ctx* c = prepare_launch(rt, fl);
     const float o[3] = {origin.x, origin.y, origin.z}, f[3] = {fwd.x, fwd.y, fwd.z}, u[3] = {up.x, up.y, up.z},
                 r[3] = {right.x, right.y, right.z};
     ok(vxrt_render(c, w, h, d_screen_texture, o, f, u, r, &fl), "vxrt_render");
     ok(vxrt_synchronize(c), "vxrt_synchronize");  // RenderScreen returns with the frame finished (Renderer.cu:327)
+}
+
+void RenderScreens(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, const ScreenView* views, uint32_t count)
+{
+    vxrt_render_flags fl;
+    vxrt_ctx* c = prepare_launch(rt, fl);
+    std::vector<vxrt_view> v(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        std::memset(&v[i], 0, sizeof(vxrt_view));
+        v[i].d_fb = views[i].d_screen_texture;
+        const float3 in[4] = {views[i].origin, views[i].camera_fwd, views[i].camera_up, views[i].camera_right};
+        float* out[4] = {v[i].origin, v[i].fwd, v[i].up, v[i].right};
+        for (int k = 0; k < 4; ++k) {
+            out[k][0] = in[k].x;
+            out[k][1] = in[k].y;
+            out[k][2] = in[k].z;
+        }
+        v[i].frame_number = -1;  // each view takes the next FrameNumber, as successive RenderScreen calls would
+    }
+    for (uint32_t first = 0; first < count; first += 16) {  // one launch takes up to 16 views
+        const uint32_t n = count - first < 16u ? count - first : 16u;
+        ok(vxrt_render_views(c, w, h, n, v.data() + first, &fl), "vxrt_render_views");
+    }
+    ok(vxrt_synchronize(c), "vxrt_synchronize");
 }
 
 }  // namespace Graphics
