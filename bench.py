@@ -252,6 +252,26 @@ def main():
             result["rehearsal"] = {"gathered_frame_equals_single_gpu_frame": bool(torch.equal(full, frames)),
                                    "note": "all ranks on one GPU over gloo: value is not a measurement"}
             ctx.frame_stats()
+        if world == 1 and V > 1:
+            # the same frames with the reference's call pattern, one view per launch (vxrt_render), for comparison
+            torch.cuda.synchronize()
+            ctx.frame_stats()
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                for v in views_of(args.warmup + k, frames):
+                    ctx.RenderScreen(W, H, v["fb"], v["origin"], v["fwd"], v["up"], v["right"],
+                                     vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,
+                                                      bounce_all_hits=bool(args.bounce_all_hits),
+                                                      bounce_depth=args.bounce_depth, frame_number=v["frame_number"]))
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            s1 = ctx.frame_stats()
+            assert s1.total_rays() == rays_local, "ray counts differ between multi-view and single-view launches"
+            result["one_view_per_launch"] = {
+                "value": round(s1.total_rays() / dt1 / 1e6, 2), "unit": "Mrays/s",
+                "ms_per_frame": round(dt1 / (args.steps * V) * 1e3, 4),
+                "roofline_frac": round(bytes_total / dt1 / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "same frames, one vxrt_render launch per frame (the reference's RenderScreen call pattern)"}
         if args.cpu_baseline == "auto" and world == 1:
             result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts)
     if world > 1:
