@@ -389,7 +389,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             if (T.st == ST_BOX)
                 T.phase_box(W);
         }
-        T.step(W);
+        // Two probes per vote round: the ballots, votes and branches of a round are paid once per two steps, and the
+        // parked phases see twice the arrivals per vote (measured +5.5 % over one step per round; three: +5 %, four: +2 %)
+        for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
+            T.step(W);
     }
 
     const unsigned long long s0 = n_primary, s1 = n_shadow, s2 = n_bounce, s3 = n_hits;

@@ -49,6 +49,9 @@ __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_
 // Per-phase thresholds, from a sweep on the bench workload: the expensive phases (ray finished ~450 VALU, end of
 // walk ~130) wait until their lanes are a third of the live ones, the cheap tight-box test (~60) runs at a fifth.
 // (2,2,4) against (4,4,4): +2 % at 1080p, +5 % at 4K; waiting longer (1) or running sooner (6..12) both lose.
+#ifndef VXRT_STEPS_PER_ROUND
+#define VXRT_STEPS_PER_ROUND 2  // probes per vote round (vxrt_persist.hpp)
+#endif
 #ifndef VXRT_VOTE_NEXT
 #define VXRT_VOTE_NEXT 2
 #endif
@@ -418,7 +421,8 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
             row[5] = __float_as_uint(T.tn_x); row[6] = __float_as_uint(T.tn_y); row[7] = __float_as_uint(T.tn_z);
             row[8] = (unsigned)T.steps; row[9] = (unsigned)T.total; row[10] = __float_as_uint(T.ws.x); row[11] = __float_as_uint(T.ws.y);
         }
-        T.step(W);
+        for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
+            T.step(W);
     }
     T.result(W, out);
     if (STATS) {
