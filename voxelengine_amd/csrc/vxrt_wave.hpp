@@ -7,10 +7,10 @@
 //
 //  * ONE loop.  Every iteration performs one cell probe + one DDA advance for every walking lane, whether it is
 //    on the coarse grid or inside a brick; lanes on different levels share the same vector instructions.
-//  * The hot path (WaveTracer::step) is straight-line and predicated: lane conditions live in VGPRs as 0/1
-//    integers and are combined with vector AND/OR, state changes are arithmetic on a small state code, values are
-//    committed with v_cndmask.  No exec-mask branches; the occupancy word of the (clamped) current cell is loaded
-//    unconditionally, one global_load_dword per lane per iteration.
+//  * The hot path (WaveTracer::step) is straight-line and predicated: lane conditions are bools combined with
+//    non-short-circuit & and | (wave masks in scalar registers, combined by the scalar unit), values and the small
+//    state code are committed with v_cndmask.  No exec-mask branches; the occupancy word of the (clamped) current
+//    cell is loaded unconditionally, one global_load_dword per lane per probe.
 //  * The rare, expensive events -- tight-box slab test on an occupied coarse cell (ST_BOX) and the end-of-walk
 //    transitions: brick entry, brick exit + re-seed with the ulp nudge, ray end (ST_END) -- PARK the lane.
 //    A __ballot vote runs a parked phase only when enough lanes wait for it (or nobody can walk), so its
@@ -310,60 +310,61 @@ struct WaveTracer {
         nc_axis = box_hit ? packed : nc_axis;
     }
 
-    // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane
+    // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane.  Lane
+    // conditions are bools combined with non-short-circuit & and |: the compiler keeps them as wave masks in scalar
+    // registers and combines them on the scalar unit, off the vector-instruction budget (13 vector instructions fewer
+    // per two steps than the same logic on 0/1 integers in vector registers; +1 %)
     __device__ __forceinline__ void step(const WorldView& W)
     {
-        const uint32_t w = (st == ST_WALK) ? 1u : 0u;
-        // 0 <= cell < dim + pad on all three axes, as one sign test: every (cell - lim) negative, no cell negative
+        const bool w = st == ST_WALK;
         const int in_bits = (cell_x - lim_x) & (cell_y - lim_y) & (cell_z - lim_z) & ~(cell_x | cell_y | cell_z);
-        const uint32_t in = (uint32_t)in_bits >> 31;
-        // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); an out-of-range
-        // lane reads word 0 instead, so the unconditional load below always has a valid address
+        const bool in = in_bits < 0;
         const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
         const uint32_t idx_raw = tiled_index(qx, qy, qz, tw, twh);
         const uint32_t idx = in ? idx_raw : 0u;
         const uint32_t word = bits[idx >> 5];
-        const uint32_t solid = (word >> (idx & 31u)) & 1u & ~skip;
+        const bool is_fine = fine != 0u, skipping = skip != 0u;
+        const bool solid = (((word >> (idx & 31u)) & 1u) != 0u) & !skipping;
         if (STATS) {
-            const uint32_t probed = w & in & ~skip;
-            cnt.fine_probes += probed & fine;
-            cnt.coarse_probes += probed & ~fine;
+            const bool probed = w & in & !skipping;
+            cnt.fine_probes += (probed & is_fine) ? 1u : 0u;
+            cnt.coarse_probes += (probed & !is_fine) ? 1u : 0u;
         }
-        const uint32_t leave_oob = w & (in ^ 1u);            // left the grid / brick: isOutOfBounds (:283-287)
-        const uint32_t leave_hit = w & in & solid & fine;     // solid voxel inside a brick (:276-280)
-        const uint32_t park = w & in & solid & (fine ^ 1u);   // occupied coarse cell: tight-box test pending
-        const uint32_t adv = w & in & (solid ^ 1u);
-        skip = skip & (w ^ 1u);
+        const bool leave_oob = w & !in;
+        const bool leave_hit = w & in & solid & is_fine;
+        const bool park = w & in & solid & !is_fine;
+        const bool adv = w & in & !solid;
+        skip = w ? 0u : skip;
 
-        // DDA advance (:293-322), computed for every lane, committed where adv
         const bool lt_xy = tn_x < tn_y, lt_xz = tn_x < tn_z, lt_yz = tn_y < tn_z;
-        const bool ax0 = lt_xy && lt_xz;
-        const bool ax1 = !lt_xy && lt_yz;  // tn_y <= tn_x && tn_y < tn_z; implies !ax0
+        const bool ax0 = lt_xy & lt_xz;
+        const bool ax1 = !lt_xy & lt_yz;
+        const bool ax2 = !(ax0 | ax1);
         const float t = ax0 ? tn_x : (ax1 ? tn_y : tn_z);
         const float crx = ax0 ? (float)(cell_x + up_x) : ws.x + (t * d.x);
         const float cry = ax1 ? (float)(cell_y + up_y) : ws.y + (t * d.y);
-        const float crz = (ax0 || ax1) ? ws.z + (t * d.z) : (float)(cell_z + up_z);
-        // region check on the crossing point, brick walks only (:325-341): [0,f]^3, step not counted
+        const float crz = ax2 ? (float)(cell_z + up_z) : ws.z + (t * d.z);
         const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
-        const uint32_t region_oob = ((cmin < 0.0f || cmax > W.ff) ? 1u : 0u) & fine & adv;
-        const uint32_t ok = adv & (region_oob ^ 1u);
-        const bool commit = adv != 0u, counted = ok != 0u;
-        cell_x += (commit && ax0) ? 2 * up_x - 1 : 0;
-        cell_y += (commit && ax1) ? 2 * up_y - 1 : 0;
-        cell_z += (commit && !ax0 && !ax1) ? 2 * up_z - 1 : 0;
-        tn_x = (commit && ax0) ? tn_x + tdx : tn_x;
-        tn_y = (commit && ax1) ? tn_y + tdy : tn_y;
-        tn_z = (commit && !ax0 && !ax1) ? tn_z + tdz : tn_z;
-        // normal code (axis+1) | 4*negative = axis + 5 - 4*up
+        const bool region_oob = ((cmin < 0.0f) | (cmax > W.ff)) & is_fine & adv;
+        const bool ok = adv & !region_oob;
+        cell_x += (adv & ax0) ? 2 * up_x - 1 : 0;
+        cell_y += (adv & ax1) ? 2 * up_y - 1 : 0;
+        cell_z += (adv & ax2) ? 2 * up_z - 1 : 0;
+        tn_x = (adv & ax0) ? tn_x + tdx : tn_x;
+        tn_y = (adv & ax1) ? tn_y + tdy : tn_y;
+        tn_z = (adv & ax2) ? tn_z + tdz : tn_z;
         const uint32_t code = ax0 ? (uint32_t)(5 - 4 * up_x) : (ax1 ? (uint32_t)(6 - 4 * up_y) : (uint32_t)(7 - 4 * up_z));
-        w_code = counted ? code : w_code;
-        point.x = counted ? crx : point.x;
-        point.y = counted ? cry : point.y;
-        point.z = counted ? crz : point.z;
-        steps += (int)ok;
-        const uint32_t exhausted = ok & (steps >= kMaxSteps ? 1u : 0u);  // walk ran out of iterations (:234)
-        wf |= leave_hit * WF_HIT | (leave_oob | region_oob) * WF_OOB;
-        st += park * ST_BOX + (leave_oob | leave_hit | region_oob | exhausted) * ST_END;  // st was ST_WALK (0) where w
+        w_code = ok ? code : w_code;
+        point.x = ok ? crx : point.x;
+        point.y = ok ? cry : point.y;
+        point.z = ok ? crz : point.z;
+        steps += ok ? 1 : 0;
+        const bool exhausted = ok & (steps >= kMaxSteps);
+        const bool oob = leave_oob | region_oob;
+        wf = leave_hit ? (wf | (uint32_t)WF_HIT) : wf;
+        wf = oob ? (wf | (uint32_t)WF_OOB) : wf;
+        const bool ending = leave_oob | leave_hit | region_oob | exhausted;
+        st = park ? (uint32_t)ST_BOX : (ending ? (uint32_t)ST_END : st);
     }
 
     // Raytrace's epilogue (:514-523)
