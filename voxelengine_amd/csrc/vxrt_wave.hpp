@@ -229,7 +229,11 @@ struct WaveTracer {
         } else {
             hit_pos = mk3(point.x + fx * W.ff, point.y + fy * W.ff, point.z + fz * W.ff);
             if (wf & WF_HIT) {  // :493-506
-                out_code = (steps == 0) ? c_code : w_code;
+                // w_code = axis + 1 of the walk's last counted step; normal code = (axis+1) | 4*negative
+                // (selects against 0, OR-ed: a chained `?:` over the three members is the selected-address trap, which
+                // demoted the whole tracer to scratch memory and cost 60 % of the frame rate)
+                const int up_last = (w_code == 1u ? up_x : 0) | (w_code == 2u ? up_y : 0) | (w_code == 3u ? up_z : 0);
+                out_code = (steps == 0) ? c_code : (w_code + 4u - 4u * (uint32_t)up_last);
                 ray_hit = true;
                 st = ST_DONE;
             } else {  // brick missed: restart the coarse walk just past it (:431-491)
@@ -317,8 +321,8 @@ struct WaveTracer {
     __device__ __forceinline__ void step(const WorldView& W)
     {
         const bool w = st == ST_WALK;
-        const int in_bits = (cell_x - lim_x) & (cell_y - lim_y) & (cell_z - lim_z) & ~(cell_x | cell_y | cell_z);
-        const bool in = in_bits < 0;
+        // 0 <= cell < dim + pad on all three axes: unsigned compares (a negative cell is a huge unsigned)
+        const bool in = ((uint32_t)cell_x < (uint32_t)lim_x) & ((uint32_t)cell_y < (uint32_t)lim_y) & ((uint32_t)cell_z < (uint32_t)lim_z);
         const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
         const uint32_t idx_raw = tiled_index(qx, qy, qz, tw, twh);
         const uint32_t idx = in ? idx_raw : 0u;
@@ -353,8 +357,7 @@ struct WaveTracer {
         tn_x = (adv & ax0) ? tn_x + tdx : tn_x;
         tn_y = (adv & ax1) ? tn_y + tdy : tn_y;
         tn_z = (adv & ax2) ? tn_z + tdz : tn_z;
-        const uint32_t code = ax0 ? (uint32_t)(5 - 4 * up_x) : (ax1 ? (uint32_t)(6 - 4 * up_y) : (uint32_t)(7 - 4 * up_z));
-        w_code = ok ? code : w_code;
+        w_code = ok ? (ax0 ? 1u : (ax1 ? 2u : 3u)) : w_code;  // the axis; its sign is applied at the end of the walk
         point.x = ok ? crx : point.x;
         point.y = ok ? cry : point.y;
         point.z = ok ? crz : point.z;
