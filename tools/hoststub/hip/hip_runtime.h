@@ -16,6 +16,9 @@ struct uint2 { uint32_t x, y; };
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+typedef unsigned long long lanemask_t;  // one lane on the host: bit 0
+static inline lanemask_t lane_mask(bool p) { return p ? 1ull : 0ull; }
+static inline bool lane_test(lanemask_t m) { return (m & 1ull) != 0ull; }
 static inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 static inline uint32_t __umul24(uint32_t a, uint32_t b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }

@@ -64,6 +64,15 @@ struct RayCounters {
 // intrinsic because a C cast is undefined out of range, and such values do occur (1/d overflows for denormal d).
 __device__ __forceinline__ int f2i(float v) { return __float2int_rz(v); }
 
+// Lane conditions as explicit wave masks: lane_mask(p) is the 64-bit mask of p over the wave (a v_cmp result as it
+// is), masks combine with & | ~ on the scalar unit, lane_test(m) reads this lane's bit back as a condition for a
+// select.  Only for code the whole wave executes together (all lanes active).
+#ifndef VXRT_HOST_CHECK
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ lanemask_t lane_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_test(lanemask_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+#endif
+
 // 8x8x8 tiled-linear bit address (GetSampleIndex, VolumeRaytracer.cuh:107-131)
 #ifndef VXRT_HOST_CHECK  // tools/host_wave_check.cpp runs this header on the host and brings its own mad24
 __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)

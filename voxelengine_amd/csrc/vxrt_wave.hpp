@@ -315,59 +315,66 @@ struct WaveTracer {
     }
 
     // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane.  Lane
-    // conditions are bools combined with non-short-circuit & and |: the compiler keeps them as wave masks in scalar
-    // registers and combines them on the scalar unit, off the vector-instruction budget (13 vector instructions fewer
-    // per two steps than the same logic on 0/1 integers in vector registers; +1 %)
+    // conditions are explicit wave masks (lane_mask / lane_test, vxrt_device.hpp): each compare is one v_cmp whose
+    // result IS the mask, all the logic between them runs on the scalar unit, and values are committed with
+    // v_cndmask -- no exec-mask branches and no 0/1 integers in vector registers.  (Written with bool & | the
+    // compiler still materialised several conditions as 0/1 vector integers; with && || it built branches.)
     __device__ __forceinline__ void step(const WorldView& W)
     {
-        const bool w = st == ST_WALK;
+        const lanemask_t w = lane_mask(st == ST_WALK);
         // 0 <= cell < dim + pad on all three axes: unsigned compares (a negative cell is a huge unsigned)
-        const bool in = ((uint32_t)cell_x < (uint32_t)lim_x) & ((uint32_t)cell_y < (uint32_t)lim_y) & ((uint32_t)cell_z < (uint32_t)lim_z);
+        const lanemask_t in = lane_mask((uint32_t)cell_x < (uint32_t)lim_x) & lane_mask((uint32_t)cell_y < (uint32_t)lim_y) &
+                              lane_mask((uint32_t)cell_z < (uint32_t)lim_z);
+        // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); an out-of-range
+        // lane reads word 0 instead, so the unconditional load below always has a valid address
         const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
         const uint32_t idx_raw = tiled_index(qx, qy, qz, tw, twh);
-        const uint32_t idx = in ? idx_raw : 0u;
+        const uint32_t idx = lane_test(in) ? idx_raw : 0u;
         const uint32_t word = bits[idx >> 5];
-        const bool is_fine = fine != 0u, skipping = skip != 0u;
-        const bool solid = (((word >> (idx & 31u)) & 1u) != 0u) & !skipping;
+        const lanemask_t is_fine = lane_mask(fine != 0u), skipping = lane_mask(skip != 0u);
+        const lanemask_t solid = lane_mask(((word >> (idx & 31u)) & 1u) != 0u) & ~skipping;
         if (STATS) {
-            const bool probed = w & in & !skipping;
-            cnt.fine_probes += (probed & is_fine) ? 1u : 0u;
-            cnt.coarse_probes += (probed & !is_fine) ? 1u : 0u;
+            const lanemask_t probed = w & in & ~skipping;
+            cnt.fine_probes += lane_test(probed & is_fine) ? 1u : 0u;
+            cnt.coarse_probes += lane_test(probed & ~is_fine) ? 1u : 0u;
         }
-        const bool leave_oob = w & !in;
-        const bool leave_hit = w & in & solid & is_fine;
-        const bool park = w & in & solid & !is_fine;
-        const bool adv = w & in & !solid;
-        skip = w ? 0u : skip;
+        const lanemask_t leave_oob = w & ~in;                       // left the grid / brick: isOutOfBounds (:283-287)
+        const lanemask_t leave_hit = w & in & solid & is_fine;      // solid voxel inside a brick (:276-280)
+        const lanemask_t park = w & in & solid & ~is_fine;          // occupied coarse cell: tight-box test pending
+        const lanemask_t adv = w & in & ~solid;
+        skip = lane_test(w) ? 0u : skip;
 
-        const bool lt_xy = tn_x < tn_y, lt_xz = tn_x < tn_z, lt_yz = tn_y < tn_z;
-        const bool ax0 = lt_xy & lt_xz;
-        const bool ax1 = !lt_xy & lt_yz;
-        const bool ax2 = !(ax0 | ax1);
-        const float t = ax0 ? tn_x : (ax1 ? tn_y : tn_z);
-        const float crx = ax0 ? (float)(cell_x + up_x) : ws.x + (t * d.x);
-        const float cry = ax1 ? (float)(cell_y + up_y) : ws.y + (t * d.y);
-        const float crz = ax2 ? (float)(cell_z + up_z) : ws.z + (t * d.z);
+        // DDA advance (:293-322), computed for every lane, committed where adv
+        const lanemask_t lt_xy = lane_mask(tn_x < tn_y), lt_xz = lane_mask(tn_x < tn_z), lt_yz = lane_mask(tn_y < tn_z);
+        const lanemask_t ax0 = lt_xy & lt_xz;
+        const lanemask_t ax1 = ~lt_xy & lt_yz;  // tn_y <= tn_x && tn_y < tn_z; implies !ax0
+        const lanemask_t ax2 = ~(ax0 | ax1);
+        const bool on0 = lane_test(ax0), on1 = lane_test(ax1), on2 = lane_test(ax2);
+        const float t = on0 ? tn_x : (on1 ? tn_y : tn_z);
+        const float crx = on0 ? (float)(cell_x + up_x) : ws.x + (t * d.x);
+        const float cry = on1 ? (float)(cell_y + up_y) : ws.y + (t * d.y);
+        const float crz = on2 ? (float)(cell_z + up_z) : ws.z + (t * d.z);
+        // region check on the crossing point, brick walks only (:325-341): [0,f]^3, step not counted
         const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
-        const bool region_oob = ((cmin < 0.0f) | (cmax > W.ff)) & is_fine & adv;
-        const bool ok = adv & !region_oob;
-        cell_x += (adv & ax0) ? 2 * up_x - 1 : 0;
-        cell_y += (adv & ax1) ? 2 * up_y - 1 : 0;
-        cell_z += (adv & ax2) ? 2 * up_z - 1 : 0;
-        tn_x = (adv & ax0) ? tn_x + tdx : tn_x;
-        tn_y = (adv & ax1) ? tn_y + tdy : tn_y;
-        tn_z = (adv & ax2) ? tn_z + tdz : tn_z;
-        w_code = ok ? (ax0 ? 1u : (ax1 ? 2u : 3u)) : w_code;  // the axis; its sign is applied at the end of the walk
-        point.x = ok ? crx : point.x;
-        point.y = ok ? cry : point.y;
-        point.z = ok ? crz : point.z;
-        steps += ok ? 1 : 0;
-        const bool exhausted = ok & (steps >= kMaxSteps);
-        const bool oob = leave_oob | region_oob;
-        wf = leave_hit ? (wf | (uint32_t)WF_HIT) : wf;
-        wf = oob ? (wf | (uint32_t)WF_OOB) : wf;
-        const bool ending = leave_oob | leave_hit | region_oob | exhausted;
-        st = park ? (uint32_t)ST_BOX : (ending ? (uint32_t)ST_END : st);
+        const lanemask_t region_oob = (lane_mask(cmin < 0.0f) | lane_mask(cmax > W.ff)) & is_fine & adv;
+        const lanemask_t ok = adv & ~region_oob;
+        const bool c0 = lane_test(adv & ax0), c1 = lane_test(adv & ax1), c2 = lane_test(adv & ax2), counted = lane_test(ok);
+        cell_x += c0 ? 2 * up_x - 1 : 0;
+        cell_y += c1 ? 2 * up_y - 1 : 0;
+        cell_z += c2 ? 2 * up_z - 1 : 0;
+        tn_x = c0 ? tn_x + tdx : tn_x;
+        tn_y = c1 ? tn_y + tdy : tn_y;
+        tn_z = c2 ? tn_z + tdz : tn_z;
+        w_code = counted ? (on0 ? 1u : (on1 ? 2u : 3u)) : w_code;  // the axis; its sign is applied at the end of the walk
+        point.x = counted ? crx : point.x;
+        point.y = counted ? cry : point.y;
+        point.z = counted ? crz : point.z;
+        steps += counted ? 1 : 0;
+        const lanemask_t exhausted = ok & lane_mask(steps >= kMaxSteps);  // walk ran out of iterations (:234)
+        wf = lane_test(leave_hit) ? (wf | (uint32_t)WF_HIT) : wf;
+        wf = lane_test(leave_oob | region_oob) ? (wf | (uint32_t)WF_OOB) : wf;
+        const lanemask_t ending = leave_oob | leave_hit | region_oob | exhausted;
+        st = lane_test(park) ? (uint32_t)ST_BOX : (lane_test(ending) ? (uint32_t)ST_END : st);
     }
 
     // Raytrace's epilogue (:514-523)
