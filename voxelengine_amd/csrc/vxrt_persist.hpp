@@ -191,21 +191,43 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             dg_iters += 1;
             dg_walk += (unsigned long long)n_walk;
             dg_drain += drained ? 1ull : 0ull;
-            const bool r_next = vote_run(n_next, n_walk + n_box + n_end, VXRT_VOTE_NEXT),
-                       r_end = vote_run(n_end, n_walk + n_box, VXRT_VOTE_END), r_box = vote_run(n_box, n_walk, VXRT_VOTE_BOX);
-            dg_runs[0] += r_next ? 1u : 0u;
-            dg_runs[1] += r_end ? 1u : 0u;
-            dg_runs[2] += r_box ? 1u : 0u;
-            dg_lanes[0] += r_next ? (unsigned)n_next : 0u;
-            dg_lanes[1] += r_end ? (unsigned)n_end : 0u;
-            dg_lanes[2] += r_box ? (unsigned)n_box : 0u;
         }
 
+        // The parked phases run box -> end -> next inside one round, each vote on fresh counts: a lane whose box test
+        // hits can enter its brick, and a lane whose ray ends can start its next ray, in the same round instead of
+        // waiting for the next round's vote (+4 % with several probes per round; with one probe per round it was +-0)
+        int c_walk = n_walk, c_box = n_box, c_end = n_end, c_next = n_next;
+        if (vote_run(c_box, c_walk, VXRT_VOTE_BOX)) {
+            if (STATS) {
+                dg_runs[2] += 1u;
+                dg_lanes[2] += (unsigned)c_box;
+            }
+            if (T.st == ST_BOX)
+                T.phase_box(W);
+            c_box = 0;
+            c_walk = __popcll(__ballot(T.st == ST_WALK));
+            c_end = __popcll(__ballot(T.st == ST_END));
+        }
+        if (vote_run(c_end, c_walk + c_box, VXRT_VOTE_END)) {
+            if (STATS) {
+                dg_runs[1] += 1u;
+                dg_lanes[1] += (unsigned)c_end;
+            }
+            if (T.st == ST_END)
+                T.phase_end(W);
+            c_end = 0;
+            c_walk = __popcll(__ballot(T.st == ST_WALK));
+            c_next = __popcll(__ballot(T.st == ST_DONE));
+        }
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
         // launch; one begin_ray at the end of the phase serves them all (its 7 divisions + square root are the
         // expensive part of this phase).
-        if (vote_run(n_next, n_walk + n_box + n_end, VXRT_VOTE_NEXT)) {
+        if (vote_run(c_next, c_walk + c_box + c_end, VXRT_VOTE_NEXT)) {
+            if (STATS) {
+                dg_runs[0] += 1u;
+                dg_lanes[0] += (unsigned)c_next;
+            }
             bool launch = false;
             bool c_hit = false, c_shadow = false, c_bounce = false;  // this lane's contribution to the ray counters
             f3 l_origin = mk3(0, 0, 0), l_dir = mk3(1, 0, 0);
@@ -381,17 +403,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             n_hits += (uint32_t)__popcll(__ballot(c_hit));
         }
 
-        if (vote_run(n_end, n_walk + n_box, VXRT_VOTE_END)) {
-            if (T.st == ST_END)
-                T.phase_end(W);
-        }
-        if (vote_run(n_box, n_walk, VXRT_VOTE_BOX)) {
-            if (T.st == ST_BOX)
-                T.phase_box(W);
-        }
         // Several probes per vote round: the ballots, votes and branches of a round are paid once, the compiler
         // overlaps the loads of consecutive steps, and the parked phases see more arrivals per vote.  Measured with the
-        // current step: 1 / 2 / 3 / 4 / 5 probes per round = 3.53 / 3.96 / 4.02 / 3.94 / 3.86 Grays/s.
+        // current step: 1 / 2 / 3 / 4 / 5 probes per round = 3.53 / 3.96 / 4.02 / 3.94 / 3.86 Grays/s; with the phase
+        // cascade above 2 / 3 / 4 / 5 / 6 = 4.06 / 4.18 / 4.21 / 4.21 / 4.19.
         for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
             T.step(W);
     }

@@ -7,10 +7,10 @@
 //
 //  * ONE loop.  Every iteration performs one cell probe + one DDA advance for every walking lane, whether it is
 //    on the coarse grid or inside a brick; lanes on different levels share the same vector instructions.
-//  * The hot path (WaveTracer::step) is straight-line and predicated: lane conditions are bools combined with
-//    non-short-circuit & and | (wave masks in scalar registers, combined by the scalar unit), values and the small
-//    state code are committed with v_cndmask.  No exec-mask branches; the occupancy word of the (clamped) current
-//    cell is loaded unconditionally, one global_load_dword per lane per probe.
+//  * The hot path (WaveTracer::step) is straight-line and predicated: lane conditions are explicit wave masks
+//    (ballot of a compare = the v_cmp result itself), combined on the scalar unit and handed back to v_cndmask by
+//    an inverse ballot; values and the small state code are committed with v_cndmask.  No exec-mask branches; the
+//    occupancy word of the (clamped) current cell is loaded unconditionally, one global_load_dword per lane per probe.
 //  * The rare, expensive events -- tight-box slab test on an occupied coarse cell (ST_BOX) and the end-of-walk
 //    transitions: brick entry, brick exit + re-seed with the ulp nudge, ray end (ST_END) -- PARK the lane.
 //    A __ballot vote runs a parked phase only when enough lanes wait for it (or nobody can walk), so its
@@ -50,7 +50,7 @@ __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_
 // walk ~130) wait until their lanes are a third of the live ones, the cheap tight-box test (~60) runs at a fifth.
 // (2,2,4) against (4,4,4): +2 % at 1080p, +5 % at 4K; waiting longer (1) or running sooner (6..12) both lose.
 #ifndef VXRT_STEPS_PER_ROUND
-#define VXRT_STEPS_PER_ROUND 3  // probes per vote round (vxrt_persist.hpp)
+#define VXRT_STEPS_PER_ROUND 4  // probes per vote round (vxrt_persist.hpp)
 #endif
 #ifndef VXRT_VOTE_NEXT
 #define VXRT_VOTE_NEXT 2
