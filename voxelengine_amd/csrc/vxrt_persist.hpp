@@ -97,6 +97,9 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& 
     }
 }
 
+#ifndef VXRT_SUBROUNDS
+#define VXRT_SUBROUNDS 2  // groups of VXRT_STEPS_PER_ROUND probes per round
+#endif
 #ifndef VXRT_PERSIST_OCC
 #define VXRT_PERSIST_OCC 4  // waves per SIMD the register budget is sized for (128 VGPRs)
 #endif
@@ -403,12 +406,40 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             n_hits += (uint32_t)__popcll(__ballot(c_hit));
         }
 
-        // Several probes per vote round: the ballots, votes and branches of a round are paid once, the compiler
-        // overlaps the loads of consecutive steps, and the parked phases see more arrivals per vote.  Measured with the
-        // current step: 1 / 2 / 3 / 4 / 5 probes per round = 3.53 / 3.96 / 4.02 / 3.94 / 3.86 Grays/s; with the phase
-        // cascade above 2 / 3 / 4 / 5 / 6 = 4.06 / 4.18 / 4.21 / 4.21 / 4.19.
-        for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
-            T.step(W);
+        // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS groups of VXRT_STEPS_PER_ROUND probes with
+        // the cheap half of the cascade (box, end on fresh votes) between the groups: the ballots and branches of a
+        // vote are paid once per group, box/end lanes wait at most one group, and the expensive ray-finished phase
+        // is voted once per round.  Measured (groups x probes): 1x1 3.53, 1x2 3.96, 1x3 4.02 Grays/s without the
+        // cascade; with it 1x3 4.18, 1x4 4.21, 2x2 4.31, 2x3 and 2x4 the same, 3x3 4.37, 3x2 4.12 (register allocation),
+        // 4x2 falls into scratch.  The same schedule as a rolled loop (vote the ray-finished phase every 2nd or 3rd
+        // round of 2 probes) pays the round's four ballots and the loop branch per group: 4.02.
+        for (int g = 0; g < VXRT_SUBROUNDS; ++g) {
+            if (g > 0) {
+                int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
+                    m_e = __popcll(__ballot(T.st == ST_END));
+                if (vote_run(m_b, m_w, VXRT_VOTE_BOX)) {
+                    if (STATS) {
+                        dg_runs[2] += 1u;
+                        dg_lanes[2] += (unsigned)m_b;
+                    }
+                    if (T.st == ST_BOX)
+                        T.phase_box(W);
+                    m_b = 0;
+                    m_w = __popcll(__ballot(T.st == ST_WALK));
+                    m_e = __popcll(__ballot(T.st == ST_END));
+                }
+                if (vote_run(m_e, m_w + m_b, VXRT_VOTE_END)) {
+                    if (STATS) {
+                        dg_runs[1] += 1u;
+                        dg_lanes[1] += (unsigned)m_e;
+                    }
+                    if (T.st == ST_END)
+                        T.phase_end(W);
+                }
+            }
+            for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
+                T.step(W);
+        }
     }
 
     const unsigned long long s0 = n_primary, s1 = n_shadow, s2 = n_bounce, s3 = n_hits;

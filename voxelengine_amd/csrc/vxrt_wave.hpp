@@ -50,7 +50,7 @@ __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_
 // walk ~130) wait until their lanes are a third of the live ones, the cheap tight-box test (~60) runs at a fifth.
 // (2,2,4) against (4,4,4): +2 % at 1080p, +5 % at 4K; waiting longer (1) or running sooner (6..12) both lose.
 #ifndef VXRT_STEPS_PER_ROUND
-#define VXRT_STEPS_PER_ROUND 4  // probes per vote round (vxrt_persist.hpp)
+#define VXRT_STEPS_PER_ROUND 2  // probes per group between votes (vxrt_persist.hpp runs VXRT_SUBROUNDS groups per round)
 #endif
 #ifndef VXRT_VOTE_NEXT
 #define VXRT_VOTE_NEXT 2
