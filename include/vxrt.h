@@ -133,7 +133,8 @@ typedef struct vxrt_frame_stats {
     uint64_t dbg[12];       /* wave-loop diagnostics of collect_stats launches, summed over waves: [0] iterations,
                                [1] walking lanes over those iterations, [2] end-of-walk / [3] tight-box / [4] ray-finished
                                phase executions, [5..7] lanes those executions served (same order); persistent kernel
-                               only: [8] wave lifetime in 100 MHz ticks, [9] iterations after the tile queue ran dry */
+                               only: [8] wave lifetime in 100 MHz ticks, [9] iterations after the tile queue ran dry, [10] ticks inside
+                               the ray-finished phase, [11] ticks inside the box and end-of-walk phases */
 } vxrt_frame_stats;
 
 typedef struct vxrt_render_flags {

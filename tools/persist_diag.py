@@ -49,3 +49,5 @@ for cname, frac, euler in bench.CAMERAS:
     print("    phase executions per 100 iterations (lanes served per execution): next %.1f (%.1f)  end %.1f (%.1f)  box %.1f (%.1f)" % (
         100.0 * next_r / max(iters, 1), next_l / max(next_r, 1), 100.0 * end_r / max(iters, 1), end_l / max(end_r, 1),
         100.0 * box_r / max(iters, 1), box_l / max(box_r, 1)), flush=True)
+    print("    share of wave time: ray-finished phase %.1f%%  box+end phases %.1f%%  (rest: probes, votes, queue)" % (
+        100.0 * int(st.dbg[10]) / max(life, 1), 100.0 * int(st.dbg[11]) / max(life, 1)), flush=True)

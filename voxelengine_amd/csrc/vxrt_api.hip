@@ -604,7 +604,8 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     out->dbg[7] = h[vxrt::kStatDbgNextLanes];
     out->dbg[8] = h[vxrt::kStatDbgLifetime];
     out->dbg[9] = h[vxrt::kStatDbgDrained];
-    out->dbg[10] = out->dbg[11] = 0;
+    out->dbg[10] = h[vxrt::kStatDbgNextTicks];
+    out->dbg[11] = h[vxrt::kStatDbgParkTicks];
     return VXRT_OK;
 }
 

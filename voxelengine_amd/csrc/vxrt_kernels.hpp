@@ -24,6 +24,8 @@ enum StatSlot {
     kStatDbgNextLanes,
     kStatDbgLifetime,   // persistent kernel: wave lifetime, 100 MHz ticks summed over waves
     kStatDbgDrained,    // persistent kernel: iterations after the tile queue ran dry
+    kStatDbgNextTicks,  // persistent kernel: 100 MHz ticks inside the ray-finished phase, summed over waves
+    kStatDbgParkTicks,  // ... inside the box and end-of-walk phases
     kStatCount
 };
 

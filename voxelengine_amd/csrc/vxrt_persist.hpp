@@ -97,6 +97,19 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& 
     }
 }
 
+// the ray origin alone (perspective: the camera; ortho: per pixel) -- what shading and the debug view need of a
+// pixel's camera ray once the primary ray has been traced
+__device__ __forceinline__ f3 camera_origin(const RenderArgs& A, const LaneView& V, int x, int y)
+{
+    f3 origin = V.origin;
+    if (A.ortho) {
+        const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
+        origin = origin + ((V.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+        origin = origin + (V.up * (v * 2 - 1)) * A.ortho_y;
+    }
+    return origin;
+}
+
 #ifndef VXRT_SUBROUNDS
 #define VXRT_SUBROUNDS 2  // groups of VXRT_STEPS_PER_ROUND probes per round
 #endif
@@ -143,6 +156,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
     unsigned long long dg_iters = 0, dg_walk = 0, dg_drain = 0;  // STATS only: loop diagnostics
     unsigned int dg_runs[3] = {0, 0, 0}, dg_lanes[3] = {0, 0, 0};  // next / end / box phase executions, lanes served
     const unsigned long long dg_t0 = STATS ? wall_clock64() : 0ull;
+    unsigned long long dg_next_ticks = 0, dg_park_ticks = 0;
 #ifdef VXRT_TAIL_DEBUG
     unsigned long long px_t0 = 0;
 #endif
@@ -151,8 +165,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
     const f3 sray = unit3(L);
 
     // store one finished pixel (setPixelColor + the debug overlays of screenDispatch, Renderer.cu:213-275)
-    auto store_pixel = [&](const PixelCoords& pc, const LaneView& V, f3 origin, f3 ray, bool hit, f3 normal, f3 pos,
-                           f3 shaded) {
+    // `shaded`: the shaded colour of a hit pixel; for a miss, the camera ray's direction (kept in `color` since launch)
+    auto store_pixel = [&](const PixelCoords& pc, const LaneView& V, f3 origin, bool hit, f3 normal, f3 pos, f3 shaded) {
         PixelSink sink{A, pc.out_row, V.fb, V.color_aov};
         const int Wd = (int)A.width, Hd = (int)A.height;
         if (hit) {
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 sink.put(pc.x, pc.y, c);
             }
         } else {
-            sink.put(pc.x, pc.y, ray);  // Renderer.cu:254-258
+            sink.put(pc.x, pc.y, shaded);  // the ray direction, Renderer.cu:254-258
         }
         if (pc.tx == (A.width >> 1) && pc.ty == (A.height >> 1))  // crosshair on launch coordinates, :261-268
             sink.put(pc.x, pc.y, mk3(10, 10, 10));
@@ -204,9 +218,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             if (STATS) {
                 dg_runs[2] += 1u;
                 dg_lanes[2] += (unsigned)c_box;
+                dg_park_ticks -= wall_clock64();
             }
             if (T.st == ST_BOX)
                 T.phase_box(W);
+            if (STATS)
+                dg_park_ticks += wall_clock64();
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
             c_end = __popcll(__ballot(T.st == ST_END));
@@ -215,9 +232,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             if (STATS) {
                 dg_runs[1] += 1u;
                 dg_lanes[1] += (unsigned)c_end;
+                dg_park_ticks -= wall_clock64();
             }
             if (T.st == ST_END)
                 T.phase_end(W);
+            if (STATS)
+                dg_park_ticks += wall_clock64();
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
             c_next = __popcll(__ballot(T.st == ST_DONE));
@@ -230,6 +250,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             if (STATS) {
                 dg_runs[0] += 1u;
                 dg_lanes[0] += (unsigned)c_next;
+                dg_next_ticks -= wall_clock64();
             }
             bool launch = false;
             bool c_hit = false, c_shadow = false, c_bounce = false;  // this lane's contribution to the ray counters
@@ -238,8 +259,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             if (T.st == ST_DONE && stage != PX_NONE) {
                 const LaneView V = lane_view(MULTI ? px_row >> 16 : 0u);
                 const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
-                f3 origin, ray;
-                camera_ray(A, V, pc.x, pc.y, origin, ray);
+                const f3 origin = camera_origin(A, V, pc.x, pc.y);
                 TraceResult r;
                 T.result(W, r);
                 bool finalize = false, do_shade = false, shadowed = false, bounce = false, bounce2 = false;
@@ -251,7 +271,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                         V.hit_aov[(size_t)pc.out_row * A.width + (size_t)pc.x] =
                             r.hit ? (long long)r.vx + (long long)W.X * ((long long)r.vy + (long long)W.Y * (long long)r.vz) : -1ll;
                     c_hit = r.hit;
-                    color = mk3(0, 0, 0);
+                    if (r.hit)
+                        color = mk3(0, 0, 0);  // a miss keeps the ray direction stored at launch: it is the pixel's colour
                     if (!(r.hit && A.mode == 0)) {
                         stage = r.hit ? PX_PRIMARY : PX_NONE;  // remember hit/miss for the store below
                         finalize = true;
@@ -329,7 +350,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     stage = bounce2 ? PX_BOUNCE2 : PX_BOUNCE;
                 }
                 if (finalize) {
-                    store_pixel(pc, V, origin, ray, stage != PX_NONE, normal, position, color);
+                    store_pixel(pc, V, origin, stage != PX_NONE, normal, position, color);
 #ifdef VXRT_TAIL_DEBUG  // development: when each pixel's chain started / ended (100 MHz ticks), and its primary steps
                     if (STATS && V.color_aov) {
                         float* o = V.color_aov + ((size_t)pc.out_row * A.width + (size_t)pc.x) * 3;
@@ -388,6 +409,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                 const LaneView V = lane_view(MULTI ? px_row >> 16 : 0u);
                 const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
                 camera_ray(A, V, pc.x, pc.y, l_origin, l_dir);
+                color = l_dir;  // the pixel's colour if the primary ray misses (Renderer.cu:254-258)
                 l_max = kMaxSteps;
                 launch = true;
                 stage = PX_PRIMARY;
@@ -404,6 +426,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             n_shadow += (uint32_t)__popcll(__ballot(c_shadow));
             n_bounce += (uint32_t)__popcll(__ballot(c_bounce));
             n_hits += (uint32_t)__popcll(__ballot(c_hit));
+            if (STATS)
+                dg_next_ticks += wall_clock64();
         }
 
         // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS groups of VXRT_STEPS_PER_ROUND probes with
@@ -421,9 +445,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     if (STATS) {
                         dg_runs[2] += 1u;
                         dg_lanes[2] += (unsigned)m_b;
+                        dg_park_ticks -= wall_clock64();
                     }
                     if (T.st == ST_BOX)
                         T.phase_box(W);
+                    if (STATS)
+                        dg_park_ticks += wall_clock64();
                     m_b = 0;
                     m_w = __popcll(__ballot(T.st == ST_WALK));
                     m_e = __popcll(__ballot(T.st == ST_END));
@@ -432,9 +459,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     if (STATS) {
                         dg_runs[1] += 1u;
                         dg_lanes[1] += (unsigned)m_e;
+                        dg_park_ticks -= wall_clock64();
                     }
                     if (T.st == ST_END)
                         T.phase_end(W);
+                    if (STATS)
+                        dg_park_ticks += wall_clock64();
                 }
             }
             for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
@@ -465,6 +495,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
             atomicAdd(&A.stats[kStatDbgBoxLanes], (unsigned long long)dg_lanes[2]);
             atomicAdd(&A.stats[kStatDbgLifetime], wall_clock64() - dg_t0);
             atomicAdd(&A.stats[kStatDbgDrained], dg_drain);
+            atomicAdd(&A.stats[kStatDbgNextTicks], dg_next_ticks);
+            atomicAdd(&A.stats[kStatDbgParkTicks], dg_park_ticks);
         }
     }
 }
