@@ -66,11 +66,30 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="development only: all ranks share cuda:0 and the gather goes through gloo/host memory, to "
                          "exercise the N>1 code path on a one-GPU box (numbers are meaningless)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="development only: with ONE rank, run the N>1 code path anyway (packed strips, two-deep "
+                         "pipeline, gather on a one-rank NCCL communicator, de-interleave) and check the frames")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the result JSON.  Native libraries write there too (RCCL prints a version banner
+    # to fd 1 when its communicator is created), so fd 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        result = run(args)
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def run(args):
     import torch
     import torch.distributed as dist
 
@@ -97,6 +116,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    elif args.force_gather:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    sharded = world > 1 or args.force_gather
 
     X, Y, Z, F, gen, W, H, shadow, bounce = WORKLOADS[args.workload]
     ctx = vx.Context(local_rank)
@@ -120,12 +144,12 @@ def main():
     step_bytes = V * plan.shard_bytes  # what a rank contributes per step when sharded: V packed shards back to back
     local = torch.zeros(step_bytes, dtype=torch.uint8, device=dev)
     frames = torch.zeros((V, H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    shards = torch.zeros((world, step_bytes), dtype=torch.uint8, device=dev) if (rank == 0 and world > 1) else None
+    shards = torch.zeros((world, step_bytes), dtype=torch.uint8, device=dev) if (rank == 0 and sharded) else None
 
     def opts(stats=False):
         return vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, bounce_all_hits=bool(args.bounce_all_hits),
                                 bounce_depth=args.bounce_depth, strip_rows=plan.strip_rows, strip_count=world,
-                                strip_index=rank, compact=world > 1, collect_stats=stats)
+                                strip_index=rank, compact=sharded, collect_stats=stats)
 
     def views_of(i, target, hits=None):
         """the V views of step i, rendered into `target` ((V,H,W,4) frames, or V packed shards back to back)"""
@@ -146,12 +170,12 @@ def main():
 
     # N > 1: two-deep pipeline, the RCCL gather of step k overlaps the render of step k+1
     pipe = None
-    if world > 1 and not rehearse:
+    if sharded and not rehearse:
         pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames, deinterleave,
                                        nbytes=step_bytes)
 
     def step(i, ev=None):
-        target = frames if world == 1 else (pipe.local(i) if pipe else local)
+        target = frames if not sharded else (pipe.local(i) if pipe else local)
         if ev is not None:
             ev[0].record()
         ctx.RenderViews(W, H, views_of(i, target), opts())
@@ -168,7 +192,7 @@ def main():
         if pipe:
             pipe.flush()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -188,7 +212,7 @@ def main():
 
     # algorithmic bytes of the same K launches, from the probe-counting kernel variant, untimed
     for k in range(args.steps):
-        ctx.RenderViews(W, H, views_of(args.warmup + k, frames if world == 1 else local), opts(stats=True))  # `local`: scratch
+        ctx.RenderViews(W, H, views_of(args.warmup + k, frames if not sharded else local), opts(stats=True))  # `local`: scratch
     sp = ctx.frame_stats()
     assert sp.total_rays() == rays_local, "ray counts differ between the timed and the counting pass"
     bytes_local = sp.algorithmic_bytes()
@@ -241,7 +265,7 @@ def main():
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
                          "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1)},
         }
-        if rehearse:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
+        if rehearse or args.force_gather:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
             full = torch.zeros_like(frames)
             for v in views_of(args.warmup + args.steps - 1, full):
                 ctx.RenderScreen(W, H, v["fb"], v["origin"], v["fwd"], v["up"], v["right"],
@@ -250,9 +274,10 @@ def main():
                                                   frame_number=v["frame_number"]))
             torch.cuda.synchronize()
             result["rehearsal"] = {"gathered_frame_equals_single_gpu_frame": bool(torch.equal(full, frames)),
-                                   "note": "all ranks on one GPU over gloo: value is not a measurement"}
+                                   "note": "all ranks on one GPU over gloo: value is not a measurement" if rehearse
+                                   else "one-rank NCCL communicator: exercises the N>1 code path, not a scaling number"}
             ctx.frame_stats()
-        if world == 1 and V > 1:
+        if world == 1 and V > 1 and not args.force_gather:
             # the same frames with the reference's call pattern, one view per launch (vxrt_render), for comparison
             torch.cuda.synchronize()
             ctx.frame_stats()
@@ -274,11 +299,10 @@ def main():
                 "note": "same frames, one vxrt_render launch per frame (the reference's RenderScreen call pattern)"}
         if args.cpu_baseline == "auto" and world == 1:
             result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    return result if rank == 0 else None
 
 
 def host_cores() -> int:

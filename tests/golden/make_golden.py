@@ -15,6 +15,9 @@ inputs so that a change of the input builders cannot pass unnoticed):
   frame_debug.npz     160x96 frame: camera D, DEBUG_VIEW + checkerboard on stale contents, FrameNumber 2
   frame_second_bounce.npz  144x80 frame: camera B, bounce_depth 2 (this build's extension), all-hits gate
   worlds.npz          SHA-256 of the four brickmap tables of the three generators on small grids
+  config0_fan.npz     BASELINE configs[0]: ONE batch of 1 000 000 rays, Fibonacci-sphere fan from
+                      (64, 100, 64) through the 128^3 HASH_HEIGHTFIELD world, f = 8: digest of all outputs + the
+                      outputs of a 4096-ray subset
 """
 import hashlib
 import os
@@ -60,6 +63,22 @@ WORLDS = {
 }
 
 
+CONFIG0 = dict(gen=vxo.GEN_HASH_HEIGHTFIELD, dims=(128, 128, 128), factor=8, rays=1_000_000, origin=(64.0, 100.0, 64.0),
+               subset=slice(0, 1_000_000, 244))
+
+
+def config0_case():
+    c = CONFIG0
+    w = vxo.World.generate(c["gen"], c["dims"][0], c["dims"][1], c["dims"][2], c["factor"])
+    o, d = helpers.fibonacci_fan(c["rays"], c["origin"])
+    return w, o, d
+
+
+def batch_digest(r, pos_key="pos") -> str:
+    return digest(r["hit"].astype(np.uint8), r["steps"].astype(np.int32), r["voxel"].astype(np.int64),
+                  r[pos_key].view(np.uint32), r["normal"].astype(np.int8))
+
+
 def trace_case(name):
     make, n, seed = TRACES[name]
     w = make()
@@ -95,6 +114,13 @@ def main():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), inputs=digest(stale, w.coarse_bits, w.pool), fb=out["fb"],
                             hit=out["hit"], rays=np.array([st.primary_rays, st.shadow_rays, st.bounce_rays, st.primary_hits],
                                                           np.int64))
+    w, o, d = config0_case()
+    r = w.trace_batch(o, d)
+    sub = CONFIG0["subset"]
+    np.savez_compressed(os.path.join(HERE, "config0_fan.npz"), inputs=digest(o, d, w.coarse_bits, w.pool), outputs=batch_digest(r),
+                        hit=r["hit"][sub], steps=r["steps"][sub], voxel=r["voxel"][sub], pos_bits=r["pos"][sub].view(np.uint32),
+                        normal=r["normal"][sub].astype(np.int8), hits_total=np.int64(r["hit"].sum()),
+                        steps_total=np.int64(r["steps"].astype(np.int64).sum()))
     sums = {}
     for name in WORLDS:
         w = world_tables(name)

@@ -68,3 +68,16 @@ def camera(name, dims, vxo_or_engine):
     f, u, r = vxo_or_engine.get_directions(euler) if hasattr(vxo_or_engine, "get_directions") \
         else vxo_or_engine.GetDirections(euler)
     return pos, f, u, r
+
+
+def fibonacci_fan(n, origin):
+    """n rays from one origin with Fibonacci-sphere directions: the 3-D analogue of the angular fan of the
+    reference's 2-D tester (DDATestCpp/DDATestCpp.cpp:443-448, RAYS = 1000000 at :21).  Ray i points along
+    (r cos(i*ga), 1 - (2i+1)/n, r sin(i*ga)), ga = the golden angle; evaluated in binary64, stored as binary32."""
+    i = np.arange(n, dtype=np.float64)
+    y = 1.0 - (2.0 * i + 1.0) / n
+    r = np.sqrt(1.0 - y * y)
+    phi = i * (np.pi * (3.0 - np.sqrt(5.0)))
+    d = np.stack([r * np.cos(phi), y, r * np.sin(phi)], 1).astype(np.float32)
+    o = np.tile(np.asarray(origin, np.float32), (n, 1))
+    return o, d
