@@ -95,16 +95,18 @@ __device__ __forceinline__ uint32_t tiled_index(int x, int y, int z, int tw, int
 // nextafterf(v, neg ? -inf : +inf) by bit manipulation (VolumeRaytracer.cu:452-460)
 __device__ __forceinline__ float ulp_step(float v, bool neg)
 {
-    uint32_t b = __float_as_uint(v);
-    uint32_t mag = b & 0x7FFFFFFFu;
-    if (mag > 0x7F800000u)
-        return v;  // NaN
-    if (mag == 0u)
-        return __uint_as_float(neg ? 0x80000001u : 0x00000001u);
-    bool negative = (b >> 31) != 0u;
-    if (mag == 0x7F800000u && negative == neg)
-        return v;  // already at the infinity we walk toward
-    return __uint_as_float(negative == neg ? b + 1u : b - 1u);
+    // straight-line selects (it runs inside the wave tracer's end-of-walk phase, where every branch costs the
+    // whole wave an exec-mask round trip)
+    const uint32_t b = __float_as_uint(v);
+    const uint32_t mag = b & 0x7FFFFFFFu;
+    const bool negative = (b >> 31) != 0u;
+    const bool away = negative == neg;  // stepping away from zero
+    const uint32_t stepped = away ? b + 1u : b - 1u;
+    const uint32_t from_zero = neg ? 0x80000001u : 0x00000001u;
+    const uint32_t moved = mag == 0u ? from_zero : stepped;
+    // NaN stays; so does the infinity we walk toward
+    const bool keep = mag > 0x7F800000u || (mag == 0x7F800000u && away);
+    return __uint_as_float(keep ? b : moved);
 }
 
 // RayIntersectsAABB (VolumeRaytracer.cu:124-174)

@@ -204,77 +204,70 @@ struct WaveTracer {
     // parked phase: end of a walk (:395-511); call for lanes with st == ST_END
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
-        const int sgx = d.x > 0 ? 1 : -1, sgy = d.y > 0 ? 1 : -1, sgz = d.z > 0 ? 1 : -1;
+        // Straight-line selects up to the shared begin_walk: the lanes of one execution are a mix of all four cases
+        // (brick entry, coarse walk over, brick hit, brick miss), so every branch would be taken by somebody, and
+        // the branchy form (three nested short-circuit compares, three ulp_steps with early returns, ...) paid
+        // ~40 exec-mask round trips per execution for ~60 instructions of arithmetic.
         total += steps;
+        const bool is_fine = fine != 0u;
         const float fx = (float)chx, fy = (float)chy, fz = (float)chz;
-        // both continuations (enter the brick / restart the coarse walk) share ONE begin_walk below: its three
-        // IEEE divisions are the bulk of this phase
-        bool go = false;
-        uint32_t to_fine = 0u;
-        f3 ns = start;
-        if (!fine) {
-            hit_pos = mk3(point.x * W.ff, point.y * W.ff, point.z * W.ff);
-            const uint32_t ci = tiled_index(chx, chy, chz, W.ctw, W.ctwh);
-            if (wf != WF_HIT || ci == last_ci) {
-                st = ST_DONE;  // coarse miss / left the grid (:508-511), or the previous_cell guard (:402-407)
-            } else {
-                last_ci = ci;
-                ns = mk3(hit_pos.x - fx * W.ff, hit_pos.y - fy * W.ff, hit_pos.z - fz * W.ff);
-                if (STATS)
-                    cnt.brick_entries += 1;
-                bits = W.pool + (size_t)slot * W.brick_words;
-                to_fine = 1u;
-                go = true;
-            }
-        } else {
-            hit_pos = mk3(point.x + fx * W.ff, point.y + fy * W.ff, point.z + fz * W.ff);
-            if (wf & WF_HIT) {  // :493-506
-                // w_code = axis + 1 of the walk's last counted step; normal code = (axis+1) | 4*negative
-                // (selects against 0, OR-ed: a chained `?:` over the three members is the selected-address trap, which
-                // demoted the whole tracer to scratch memory and cost 60 % of the frame rate)
-                const int up_last = (w_code == 1u ? up_x : 0) | (w_code == 2u ? up_y : 0) | (w_code == 3u ? up_z : 0);
-                out_code = (steps == 0) ? c_code : (w_code + 4u - 4u * (uint32_t)up_last);
-                ray_hit = true;
-                st = ST_DONE;
-            } else {  // brick missed: restart the coarse walk just past it (:431-491)
-                start = mk3(hit_pos.x * W.inv_f, hit_pos.y * W.inv_f, hit_pos.z * W.inv_f);
-                if (wf & WF_OOB) {
-                    bool same = fx == (float)f2i(start.x) && fy == (float)f2i(start.y) && fz == (float)f2i(start.z);
-                    if (same) {
-                        start.x = ulp_step(start.x, d.x < 0);
-                        start.y = ulp_step(start.y, d.y < 0);
-                        start.z = ulp_step(start.z, d.z < 0);
-                        same = fx == (float)f2i(start.x) && fy == (float)f2i(start.y) && fz == (float)f2i(start.z);
-                        if (same) {
-                            // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from
-                            // the clamped HitCell by one when the walk started on a far face (edge rule)
-                            const int axis = nc_axis & 3;
-                            const int ncx = chx + ((nc_axis >> 2) & 1) + (axis == 0 ? sgx : 0);
-                            const int ncy = chy + ((nc_axis >> 3) & 1) + (axis == 1 ? sgy : 0);
-                            const int ncz = chz + ((nc_axis >> 4) & 1) + (axis == 2 ? sgz : 0);
-                            float gx = (float)ncx - start.x, gy = (float)ncy - start.y, gz = (float)ncz - start.z;
-                            float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
-                            if (mx < my && mx < mz)
-                                start.x += gx;
-                            else if (my < mx && my < mz)
-                                start.y += gy;
-                            else
-                                start.z += gz;
-                        }
-                    }
-                }
-                if (total < max_steps) {  // the while condition, checked only here (:386)
-                    bits = W.coarse_bits;
-                    ns = start;
-                    go = true;
-                } else {
-                    st = ST_DONE;
-                }
-            }
-        }
+        const float ox = fx * W.ff, oy = fy * W.ff, oz = fz * W.ff;  // the brick's origin in voxels
+        // coarse walk: hitPosition = point * f (:397); brick walk: point + HitCell * f (:426)
+        hit_pos.x = is_fine ? point.x + ox : point.x * W.ff;
+        hit_pos.y = is_fine ? point.y + oy : point.y * W.ff;
+        hit_pos.z = is_fine ? point.z + oz : point.z * W.ff;
+        const uint32_t ci = tiled_index(chx, chy, chz, W.ctw, W.ctwh);
+        // coarse walk ended on an occupied cell that is not the previous_cell (:399-407): enter its brick
+        const bool enter = !is_fine && wf == WF_HIT && ci != last_ci;
+        const bool fine_hit = is_fine && (wf & WF_HIT) != 0u;  // :493-506
+        const bool fine_miss = is_fine && (wf & WF_HIT) == 0u;  // restart the coarse walk just past the brick (:431-491)
+        last_ci = enter ? ci : last_ci;
+        if (STATS)
+            cnt.brick_entries += enter ? 1u : 0u;
+        // w_code = axis + 1 of the walk's last counted step; normal code = (axis+1) | 4*negative
+        // (selects against 0, OR-ed: a chained `?:` over the three members is the selected-address trap, which
+        // demoted the whole tracer to scratch memory and cost 60 % of the frame rate)
+        const int up_last = (w_code == 1u ? up_x : 0) | (w_code == 2u ? up_y : 0) | (w_code == 3u ? up_z : 0);
+        const uint32_t hit_code = (steps == 0) ? c_code : (w_code + 4u - 4u * (uint32_t)up_last);
+        out_code = fine_hit ? hit_code : out_code;
+        ray_hit = fine_hit ? true : ray_hit;
+        // brick miss: start = hitPosition / f; if the brick walk left the brick and start is still inside HitCell,
+        // nudge all three components one ulp along the ray, and if that is not enough snap one axis to NextCell
+        float sx = hit_pos.x * W.inv_f, sy = hit_pos.y * W.inv_f, sz = hit_pos.z * W.inv_f;
+        const bool same1 = (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
+        const bool nudge = fine_miss & ((wf & WF_OOB) != 0u) & same1;
+        const float ux = ulp_step(sx, d.x < 0), uy = ulp_step(sy, d.y < 0), uz = ulp_step(sz, d.z < 0);
+        sx = nudge ? ux : sx;
+        sy = nudge ? uy : sy;
+        sz = nudge ? uz : sz;
+        const bool snap = nudge & (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
+        // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from the clamped HitCell by
+        // one when the walk started on a far face (edge rule)
+        const int axis = nc_axis & 3;
+        const int ncx = chx + ((nc_axis >> 2) & 1) + (axis == 0 ? 2 * up_x - 1 : 0);
+        const int ncy = chy + ((nc_axis >> 3) & 1) + (axis == 1 ? 2 * up_y - 1 : 0);
+        const int ncz = chz + ((nc_axis >> 4) & 1) + (axis == 2 ? 2 * up_z - 1 : 0);
+        const float gx = (float)ncx - sx, gy = (float)ncy - sy, gz = (float)ncz - sz;
+        const float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
+        const bool snap_x = (mx < my) & (mx < mz);               // :475-486, in the reference's order
+        const bool snap_y = !snap_x & (my < mx) & (my < mz);
+        const bool snap_z = !snap_x & !snap_y;
+        sx = (snap & snap_x) ? sx + gx : sx;  // (a branch around this rare case measured no better)
+        sy = (snap & snap_y) ? sy + gy : sy;
+        sz = (snap & snap_z) ? sz + gz : sz;
+        start.x = fine_miss ? sx : start.x;
+        start.y = fine_miss ? sy : start.y;
+        start.z = fine_miss ? sz : start.z;
+        const bool restart = fine_miss && total < max_steps;  // the while condition, checked only here (:386)
+        const bool go = enter | restart;
+        // both continuations (enter the brick / restart the coarse walk) share ONE begin_walk: its three IEEE
+        // divisions are the bulk of this phase
+        const uint32_t* const brick = W.pool + (size_t)slot * W.brick_words;
+        bits = enter ? brick : (restart ? W.coarse_bits : bits);
+        st = go ? (uint32_t)ST_WALK : (uint32_t)ST_DONE;
         if (go) {
-            begin_walk(W, ns, to_fine);
-            st = ST_WALK;
+            const f3 ns = mk3(enter ? hit_pos.x - ox : sx, enter ? hit_pos.y - oy : sy, enter ? hit_pos.z - oz : sz);
+            begin_walk(W, ns, enter ? 1u : 0u);
         }
     }
 
