@@ -259,7 +259,9 @@ def run(args):
                 if world > 1 else "none", "rays_per_step": round(rays_total / args.steps, 1),
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
             },
-            "roofline": {"bound": "hbm", "kernel": "k_render", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "k_render_persist<false,%s,%s>" % ("true" if args.bounce_depth == 2 else "false",
+                                                                                    "true" if V > 1 else "false"),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(bytes_total / n_launch, 1),
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
