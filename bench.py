@@ -4,11 +4,14 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = one launch over the four benchmark views (cameras A-D), each a 1920x1080 frame of BASELINE.json
-configs[2]: primary ray + shadow ray for every primary hit + 1 bounce sample (reference gate `lDot == 0`),
-8192x512x8192 procedurally generated brickmap (factor 32).  `--views-per-step 1` gives the reference's one view per
-launch.  With N > 1 every view is sharded by interleaved 16-row strips, the brickmap is replicated per GPU and the
-packed strips of the step are gathered to rank 0 over RCCL in one collective (strong scaling: the frames are fixed).
+One step = one launch over a batch of 16 views (the benchmark cameras A-D in turn, every frame with its own
+FrameNumber), each a 1920x1080 frame of BASELINE.json configs[2]: primary ray + shadow ray for every primary hit +
+1 bounce sample (reference gate `lDot == 0`), 8192x512x8192 procedurally generated brickmap (factor 32).
+`--views-per-step 1` gives the reference's one view per launch (also reported in the line, `one_view_per_launch`).
+The batch is what keeps a GPU busy when it renders only 1/N of every frame: a launch's low-occupancy tail is paid
+once per launch, not once per frame.  With N > 1 every view is sharded by interleaved 16-row
+strips, the brickmap is replicated per GPU and the packed strips of the step are gathered to rank 0 over RCCL in one
+collective (strong scaling: the frames and the batch are the same at every N).
 `value` = rays actually traced by all ranks / wall time of the K timed steps (inputs resident in HBM, gather
 included).  Rank 0 prints ONE JSON line.
 """
@@ -54,12 +57,12 @@ CAMERAS = [
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--workload", default="c3_8k_1080p_shadow_bounce", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
-    ap.add_argument("--views-per-step", type=int, default=4,
+    ap.add_argument("--views-per-step", type=int, default=16,
                     help="views rendered by one launch (vxrt_render_views); 1 = one RenderScreen-style launch per frame")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
     ap.add_argument("--bounce-depth", type=int, default=1, help="2 = second bounce (BASELINE config 5; extension beyond the reference)")
@@ -237,8 +240,11 @@ def run(args):
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
-                key = {4: args.workload, 1: args.workload + "_single_view_launch"}.get(V)  # profiled launch shapes
-                traffic = json.load(open(tj)).get(key, {}).get("hbm_bytes_per_launch") if world == 1 else None
+                # profiled launch shapes: the default batch (entry `workload`, which names its views_per_launch) and V = 1
+                tab = json.load(open(tj))
+                ent = tab.get(args.workload + "_single_view_launch", {}) if V == 1 else tab.get(args.workload, {})
+                if world == 1 and ent.get("views_per_launch", 1 if V == 1 else None) == V:
+                    traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         result = {

@@ -337,6 +337,43 @@ def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
         ctx.frame_stats()
 
 
+def test_multi_view_launch_sixteen_views_back_to_back(eng, vxo):
+    """The largest launch (16 views, bench.py's default step) issued 20 times without a host sync in between: more
+    launches than the context has argument slots (16) or tile counters, each with its own frame numbers and its own
+    output buffers.  Every frame of every launch equals the single-view render of that frame."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    W, H = 200, 120
+    opts = dict(shadow=True, bounce_samples=1)
+    names = ["A", "B", "C", "D"]
+    cams = [helpers.camera(n, w.dims, vxo) for n in names]
+    launches = []
+    for k in range(20):
+        views = []
+        for j in range(16):
+            pos, f, u, r = cams[(k + j) % 4]
+            views.append(dict(fb=torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda"), origin=pos, fwd=f, up=u, right=r,
+                              frame_number=1 + 16 * k + j))
+        ctx.RenderViews(W, H, views, vx.RenderOptions(**opts))
+        launches.append(views)
+    torch.cuda.synchronize()
+    ref = {}
+    for k in (0, 7, 15, 16, 19):            # spot-check launches on both sides of the slot ring's wrap
+        for j in (0, 5, 15):
+            fn = 1 + 16 * k + j
+            pos, f, u, r = cams[(k + j) % 4]
+            fb = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            ctx.RenderScreen(W, H, fb, pos, f, u, r, vx.RenderOptions(frame_number=fn, **opts))
+            assert torch.equal(launches[k][j]["fb"], fb), (k, j)
+            ref[fn] = fb
+    # one of them against the oracle
+    pos, f, u, r = cams[(19 + 15) % 4]
+    p = vxo.make_params(W, H, pos, f, u, r, frame_number=1 + 16 * 19 + 15, shadow=1, bounce_samples=1)
+    assert np.array_equal(launches[19][15]["fb"].cpu().numpy(), w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"])
+    ctx.frame_stats()
+
+
 @pytest.mark.parametrize("gen,shape,factor", [(0, (128, 128, 128), 16), (2, (256, 256, 256), 32),
                                               (1, (128, 128, 128), 16), (2, (64, 64, 128), 8),
                                               (1, (512, 64, 64), 8)])

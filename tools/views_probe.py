@@ -22,12 +22,12 @@ ctx.build_world(gen, X, Y, Z, F)
 l = float(np.float32(1.0) / np.sqrt(np.float32(3.0), dtype=np.float32))
 ctx.SetEnvironment((l, l, l), (2, 2, 2), (0.5, 0.5, 0.5))
 cams = [(vx.GetDirections(e), (fr[0] * X, fr[1] * Y, fr[2] * Z)) for _, fr, e in bench.CAMERAS]
-for count in (1, 8):
+for count in (1, 2, 4, 8):
     plan = sharding.ShardPlan(W, H, sharding.STRIP_ROWS, count, 0)
     nbytes = plan.shard_bytes if count > 1 else W * H * 4
     o = vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, strip_rows=plan.strip_rows, strip_count=count,
                          strip_index=0, compact=count > 1)
-    for nv in (1, 2, 4, 8):
+    for nv in (1, 4, 16):
         bufs = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nv)]
 
         def launch(k):

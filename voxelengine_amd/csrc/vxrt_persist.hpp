@@ -381,6 +381,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                     if (MULTI) {
                         tile_view = tile / ntiles;
                         tile -= tile_view * ntiles;
+                        // (ranking only the last view's rows -- the only view with a tail of its own -- measured 0.8 %
+                        // slower: horizon-first order inside every view also helps the overlap between views)
                         const ViewArgs& S = A.views[tile_view];
                         if (S.row_order_n)
                             tile = (uint32_t)S.row_order[tile / ntx] * ntx + tile % ntx;
