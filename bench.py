@@ -168,8 +168,8 @@ def run(args):
         return out
 
     def deinterleave(sh, fr):
-        for j in range(V):  # shards of view j sit at byte offset j * shard_bytes of every rank's contribution
-            ctx.deinterleave_strips(W, H, plan.strip_rows, world, sh.data_ptr() + j * plan.shard_bytes, step_bytes, fr[j])
+        # one launch for the V views: the shards of view j sit at byte offset j * shard_bytes of every rank's contribution
+        ctx.deinterleave_views(W, H, plan.strip_rows, world, sh, step_bytes, plan.shard_bytes, V, fr, W * H * 4)
 
     # N > 1: two-deep pipeline, the RCCL gather of step k overlaps the render of step k+1
     pipe = None

@@ -198,6 +198,11 @@ int vxrt_frame_stats_get(vxrt_ctx *ctx, vxrt_frame_stats *out);
 int vxrt_deinterleave_strips(vxrt_ctx *ctx, uint32_t width, uint32_t height, int32_t strip_rows,
                              int32_t strip_count, const void *d_shards, uint64_t shard_stride_bytes,
                              void *d_fb, void *stream);
+/* the same for the `n_views` views of one multi-view step in ONE launch: view j's packed rows start
+ * `j * view_stride_bytes` into every shard's contribution, its frame `j * fb_stride_bytes` into d_fb */
+int vxrt_deinterleave_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, int32_t strip_rows, int32_t strip_count,
+                            const void *d_shards, uint64_t shard_stride_bytes, uint64_t view_stride_bytes,
+                            uint32_t n_views, void *d_fb, uint64_t fb_stride_bytes, void *stream);
 
 /* ---- batch query.  Replaces VoxelRaytracer3D::Raytrace + kernel dispatch
  * (VoxelRT/VolumeRaytracer.cu:95-117,574-618).  Results follow the reference

@@ -374,6 +374,26 @@ def test_multi_view_launch_sixteen_views_back_to_back(eng, vxo):
     ctx.frame_stats()
 
 
+@pytest.mark.parametrize("count,rows,views", [(2, 16, 3), (8, 16, 16), (3, 8, 5)])
+def test_deinterleave_views_equals_per_view_deinterleave(eng, count, rows, views):
+    """vxrt_deinterleave_views: the strips of all views of a multi-view step in one launch = one
+    vxrt_deinterleave_strips per view (what the gather's root runs), on a ragged frame height."""
+    vx, ctx, torch = eng
+    W, H = 256, 150
+    shard_bytes = max(vx.compact_rows(H, rows, count, i) for i in range(count)) * W * 4
+    step_bytes = views * shard_bytes
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shards = torch.randint(0, 256, (count, step_bytes), dtype=torch.uint8, device="cuda", generator=g)
+    want = torch.zeros((views, H, W, 4), dtype=torch.uint8, device="cuda")
+    for j in range(views):
+        ctx.deinterleave_strips(W, H, rows, count, shards.data_ptr() + j * shard_bytes, step_bytes, want[j])
+    got = torch.full((views, H, W, 4), 9, dtype=torch.uint8, device="cuda")
+    ctx.deinterleave_views(W, H, rows, count, shards, step_bytes, shard_bytes, views, got, W * H * 4)
+    assert torch.equal(got, want)
+    with pytest.raises(vx.VxrtError):
+        ctx.deinterleave_views(W, H, rows, count, shards, step_bytes, shard_bytes + 4, views, got, W * H * 4)
+
+
 @pytest.mark.parametrize("gen,shape,factor", [(0, (128, 128, 128), 16), (2, (256, 256, 256), 32),
                                               (1, (128, 128, 128), 16), (2, (64, 64, 128), 8),
                                               (1, (512, 64, 64), 8)])

@@ -19,7 +19,7 @@ EXPORTS = [
     "vxrt_save_world", "vxrt_load_world", "vxrt_world_file_info",
     "vxrt_set_environment", "vxrt_set_fov", "vxrt_set_ortho_window_size", "vxrt_get_directions",
     "vxrt_render_flags_default", "vxrt_render", "vxrt_render_views", "vxrt_compact_rows", "vxrt_frame_stats_get",
-    "vxrt_deinterleave_strips", "vxrt_trace_batch", "vxrt_trace_batch_host",
+    "vxrt_deinterleave_strips", "vxrt_deinterleave_views", "vxrt_trace_batch", "vxrt_trace_batch_host",
 ]
 
 
@@ -122,6 +122,8 @@ def load() -> C.CDLL:
     L.vxrt_frame_stats_get.argtypes = [C.c_void_p, C.POINTER(FrameStats)]
     L.vxrt_deinterleave_strips.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p,
                                            C.c_uint64, C.c_void_p, C.c_void_p]
+    L.vxrt_deinterleave_views.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int32, C.c_int32, C.c_void_p, C.c_uint64,
+                                          C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     L.vxrt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.POINTER(FrameStats), C.c_void_p]
     L.vxrt_trace_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,

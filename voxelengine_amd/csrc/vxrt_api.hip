@@ -18,7 +18,8 @@ namespace vxrt {
 void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
 void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
-                         uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream);
+                         uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream, uint32_t n_views = 1,
+                         unsigned long long view_stride_bytes = 0, unsigned long long fb_stride_bytes = 0);
 int build_world_on_device(struct ::vxrt_ctx* ctx, int generator, int X, int Y, int Z, int factor);
 }  // namespace vxrt
 
@@ -619,6 +620,24 @@ int vxrt_deinterleave_strips(vxrt_ctx* c, uint32_t width, uint32_t height, int32
     VX_HIP(hipSetDevice(c->device));
     vxrt::launch_deinterleave(d_shards, shard_stride_bytes, d_fb, width, height, (uint32_t)strip_rows,
                               (uint32_t)strip_count, (hipStream_t)stream);
+    VX_HIP(hipGetLastError());
+    return VXRT_OK;
+}
+
+int vxrt_deinterleave_views(vxrt_ctx* c, uint32_t width, uint32_t height, int32_t strip_rows, int32_t strip_count,
+                            const void* d_shards, uint64_t shard_stride_bytes, uint64_t view_stride_bytes, uint32_t n_views,
+                            void* d_fb, uint64_t fb_stride_bytes, void* stream)
+{
+    if (!c || !d_shards || !d_fb)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (width % 4 != 0 || shard_stride_bytes % 16 != 0 || view_stride_bytes % 16 != 0 || fb_stride_bytes % 16 != 0 ||
+        strip_rows <= 0 || strip_count <= 0)
+        return fail(VXRT_ERR_INVALID, "width must be a multiple of 4 pixels and the strides of 16 bytes");
+    if (n_views > 65535u)
+        return fail(VXRT_ERR_INVALID, "too many views");
+    VX_HIP(hipSetDevice(c->device));
+    vxrt::launch_deinterleave(d_shards, shard_stride_bytes, d_fb, width, height, (uint32_t)strip_rows, (uint32_t)strip_count,
+                              (hipStream_t)stream, n_views, view_stride_bytes, fb_stride_bytes);
     VX_HIP(hipGetLastError());
     return VXRT_OK;
 }

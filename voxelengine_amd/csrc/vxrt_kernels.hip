@@ -284,10 +284,15 @@ __global__ __launch_bounds__(256) void k_trace_batch(BatchArgs B)
 }
 
 // packed shard buffers -> full frame: 16 bytes (4 pixels) per lane, rows are whole strips
+// blockIdx.y = view of a multi-view step: view j's packed rows sit `view_stride_vec` further into every shard's
+// contribution, its frame `fb_stride_vec` further into the output
 __global__ __launch_bounds__(256) void k_deinterleave(const uint4* __restrict__ shards, unsigned long long shard_stride_vec,
                                                       uint4* __restrict__ fb, uint32_t width_vec, uint32_t height,
-                                                      uint32_t strip_rows, uint32_t strip_count)
+                                                      uint32_t strip_rows, uint32_t strip_count,
+                                                      unsigned long long view_stride_vec, unsigned long long fb_stride_vec)
 {
+    shards += (unsigned long long)blockIdx.y * view_stride_vec;
+    fb += (unsigned long long)blockIdx.y * fb_stride_vec;
     const unsigned long long total = (unsigned long long)width_vec * height;
     for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (unsigned long long)gridDim.x * blockDim.x) {
@@ -604,7 +609,8 @@ void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t
 }
 
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
-                         uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream)
+                         uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream, uint32_t n_views,
+                         unsigned long long view_stride_bytes, unsigned long long fb_stride_bytes)
 {
     uint32_t width_vec = width / 4;  // caller guarantees width % 4 == 0
     unsigned long long total = (unsigned long long)width_vec * height;
@@ -613,8 +619,10 @@ void launch_deinterleave(const void* shards, unsigned long long shard_stride_byt
         blocks = 2048;
     if (blocks == 0)
         return;
-    hipLaunchKernelGGL(k_deinterleave, dim3(blocks), dim3(256), 0, stream, (const uint4*)shards, shard_stride_bytes / 16,
-                       (uint4*)fb, width_vec, height, strip_rows, strip_count);
+    if (n_views == 0)
+        return;
+    hipLaunchKernelGGL(k_deinterleave, dim3(blocks, n_views), dim3(256), 0, stream, (const uint4*)shards, shard_stride_bytes / 16,
+                       (uint4*)fb, width_vec, height, strip_rows, strip_count, view_stride_bytes / 16, fb_stride_bytes / 16);
 }
 
 }  // namespace vxrt

@@ -214,6 +214,13 @@ class Context:
         N.check(self._L.vxrt_deinterleave_strips(self._h, width, height, strip_rows, strip_count, _ptr(d_shards),
                                                  int(shard_stride_bytes), _ptr(d_fb), _stream(stream)))
 
+    def deinterleave_views(self, width, height, strip_rows, strip_count, d_shards, shard_stride_bytes, view_stride_bytes,
+                           n_views, d_fb, fb_stride_bytes, stream: int | None = None) -> None:
+        """The strips of all `n_views` views of one multi-view step in one launch (vxrt_deinterleave_views)."""
+        N.check(self._L.vxrt_deinterleave_views(self._h, width, height, strip_rows, strip_count, _ptr(d_shards),
+                                                int(shard_stride_bytes), int(view_stride_bytes), int(n_views), _ptr(d_fb),
+                                                int(fb_stride_bytes), _stream(stream)))
+
     # ---- batch -----------------------------------------------------------------------------------
     def Raytrace(self, origins, dirs, want_stats: bool = False):
         """VoxelRaytracer3D::Raytrace (VoxelRT/VolumeRaytracer.cu:574-618) on host arrays: copy in, trace,
