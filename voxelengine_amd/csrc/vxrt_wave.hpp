@@ -64,7 +64,7 @@ __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_
 
 // One lane's ray: Raytrace-level state (:359-384), the current DDARayTraversal walk (:178-232) and the coarse
 // results that outlive the coarse walk (:399-429,:438-488).  All members live in registers.
-template <bool STATS>
+template <bool STATS, bool MASKED_LOAD = false>
 struct WaveTracer {
     // per-ray constants
     f3 d;                 // normalised direction
@@ -325,7 +325,12 @@ struct WaveTracer {
         const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
         const uint32_t idx_raw = tiled_index(qx, qy, qz, tw, twh);
         const uint32_t idx = lane_test(in) ? idx_raw : 0u;
-        const uint32_t word = bits[idx >> 5];
+        // MASKED_LOAD: only walking lanes load.  In the render kernels the load is unconditional (parked lanes re-read
+        // their last word from L1/L2; the exec-mask branch around the load costs 3.6 % of the frame rate); for a batch
+        // of incoherent rays, where every request is an HBM miss, masking it is worth +23 % (tools/batch_probe.py)
+        uint32_t word = 0u;
+        if (!MASKED_LOAD || st == ST_WALK)
+            word = bits[idx >> 5];
         const lanemask_t is_fine = lane_mask(fine != 0u), skipping = lane_mask(skip != 0u);
         const lanemask_t solid = lane_mask(((word >> (idx & 31u)) & 1u) != 0u) & ~skipping;
         if (STATS) {
@@ -391,11 +396,11 @@ struct WaveTracer {
 };
 
 // one ray per lane, entered by the whole wave at a converged point
-template <bool STATS>
+template <bool STATS, bool MASKED_LOAD = false>
 __device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
                            TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr)
 {
-    WaveTracer<STATS> T;
+    WaveTracer<STATS, MASKED_LOAD> T;
     T.init(W);
     if (active)
         T.begin_ray(W, origin, ray, max_steps);
