@@ -53,6 +53,35 @@ def test_trace_batch_random_worlds(eng, vxo, factor, size, density, seed):
     assert 0 < int(cpu["hit"].sum()) < len(o)
 
 
+@pytest.mark.parametrize("n", [262145, 300000, 524288 + 63])
+def test_trace_batch_persistent_queue(eng, vxo, n):
+    """Batches of at least 8 rays per lane of the persistent grid take k_trace_batch_persist (a queue of rays instead
+    of one ray per lane): same results, same probe counters, ragged last ticket included.  The context is created
+    with one persistent wave per CU so that these batch sizes are over the threshold."""
+    import os
+    vx, _, _ = eng
+    os.environ["VXRT_WAVES_PER_CU"] = "1"
+    try:
+        ctx = vx.Context(0)
+    finally:
+        del os.environ["VXRT_WAVES_PER_CU"]
+    try:
+        w = helpers.random_voxel_world(vxo, (128, 128, 128), 16, 0.004, 21)
+        _upload(ctx, w)
+        o, d = helpers.mixed_rays(w.dims, n, 5)
+        cpu = w.trace_batch(o, d)
+        gpu = ctx.Raytrace(o, d, want_stats=True)
+        _assert_batch_equal(gpu, cpu)
+        st = gpu["stats"]
+        assert st.primary_rays == n and st.primary_hits == int(cpu["hit"].sum())
+        assert (st.coarse_probes, st.brick_entries, st.fine_probes) == (
+            cpu["stats"].coarse_probes, cpu["stats"].brick_entries, cpu["stats"].fine_probes)
+        _assert_batch_equal(ctx.Raytrace(o, d), cpu)      # the timed instantiation
+        assert 0 < int(cpu["hit"].sum()) < n
+    finally:
+        ctx.close()
+
+
 def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     vx, ctx, _ = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)

@@ -664,6 +664,8 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     B.hit = d_hit;
     B.voxel = (long long*)d_voxel;
     B.stats = c->d_stats;
+    B.ticket = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
+    B.persistent_waves = c->persistent_waves;
     unsigned int* d_dbg = nullptr;
     if (stats && getenv("VXRT_DEBUG_TRACE")) {  // development: dump the wave loop's view of ray 0
         VX_HIP(hipMalloc((void**)&d_dbg, 400 * 12 * 4));

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 }  // namespace vxrt
 
 #include "vxrt_persist.hpp"
+#include "vxrt_batch_persist.hpp"
 
 namespace vxrt {
 
@@ -595,6 +596,18 @@ void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t
         return;
     dim3 block(256, 1, 1);
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
+    // default: persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the
+    // persistent grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
+    if (variant == 2 && B.ticket && !B.dbg_trace && B.persistent_waves && B.n >= 8ull * 64ull * B.persistent_waves) {
+        (void)hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
+        const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
+        const dim3 g((unsigned)(tickets < B.persistent_waves ? tickets : B.persistent_waves)), b(64);
+        if (stats)
+            hipLaunchKernelGGL(k_trace_batch_persist<true>, g, b, 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_trace_batch_persist<false>, g, b, 0, stream, B);
+        return;
+    }
     if (variant == 1) {
         if (stats)
             hipLaunchKernelGGL(k_trace_batch<true>, grid, block, 0, stream, B);

@@ -87,6 +87,8 @@ struct BatchArgs {
     long long* voxel;
     unsigned long long* stats;
     unsigned int* dbg_trace;  // development: per-iteration state of ray 0 (probe-counting variant only), or NULL
+    unsigned int* ticket;     // persistent batch kernel: next 64-ray ticket of the queue (zeroed per launch), or NULL
+    unsigned int persistent_waves;
 };
 
 }  // namespace vxrt
