@@ -137,7 +137,11 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
         return LaneView{A.origin, A.fwd, A.up, A.right, A.frame_number, A.fb, A.color_aov, A.hit_aov};
     };
 
+#ifdef VXRT_RENDER_MASKED_LOAD  // experiment knob: only walking lanes load (off: -3.6 % at 1080p, -3.4 % at 4K, -4 % on the 16k world)
+    WaveTracer<STATS, true> T;
+#else
     WaveTracer<STATS> T;
+#endif
     T.init(W);  // st = ST_DONE: every lane starts by asking for a pixel
     uint32_t stage = PX_NONE;
     uint32_t px_tx = 0, px_row = 0;
