@@ -18,6 +18,15 @@
 
 namespace vxrt {
 
+#ifndef VXRT_BATCH_VOTE_NEXT
+#define VXRT_BATCH_VOTE_NEXT VXRT_VOTE_NEXT
+#endif
+#ifndef VXRT_BATCH_VOTE_END
+#define VXRT_BATCH_VOTE_END VXRT_VOTE_END
+#endif
+#ifndef VXRT_BATCH_VOTE_BOX
+#define VXRT_BATCH_VOTE_BOX VXRT_VOTE_BOX
+#endif
 constexpr uint32_t kBatchTicket = 64u;  // rays per queue ticket (256 or 1024: 7 % slower on incoherent rays, no faster on short ones)
 
 template <bool STATS>
@@ -45,14 +54,14 @@ __global__ __launch_bounds__(64, 4) void k_trace_batch_persist(BatchArgs B)
             break;
         int c_walk = __popcll(m_walk), c_box = __popcll(m_box), c_end = __popcll(m_end), c_next = __popcll(m_next);
         // parked phases as a cascade on fresh votes (see k_render_persist)
-        if (vote_run(c_box, c_walk, VXRT_VOTE_BOX)) {
+        if (vote_run(c_box, c_walk, VXRT_BATCH_VOTE_BOX)) {
             if (T.st == ST_BOX)
                 T.phase_box(W);
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
             c_end = __popcll(__ballot(T.st == ST_END));
         }
-        if (vote_run(c_end, c_walk + c_box, VXRT_VOTE_END)) {
+        if (vote_run(c_end, c_walk + c_box, VXRT_BATCH_VOTE_END)) {
             if (T.st == ST_END)
                 T.phase_end(W);
             c_end = 0;
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_batch_persist(BatchArgs B)
             c_next = __popcll(__ballot(T.st == ST_DONE));
         }
         // ---- parked phase: a ray finished -> write its result, take the next ray of the ticket --------------------
-        if (vote_run(c_next, c_walk + c_box + c_end, VXRT_VOTE_NEXT)) {
+        if (vote_run(c_next, c_walk + c_box + c_end, VXRT_BATCH_VOTE_NEXT)) {
             bool c_hit = false;
             if (T.st == ST_DONE && my_ray != kNone) {
                 TraceResult t;
@@ -126,14 +135,14 @@ __global__ __launch_bounds__(64, 4) void k_trace_batch_persist(BatchArgs B)
             if (g > 0) {
                 int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
                     m_e = __popcll(__ballot(T.st == ST_END));
-                if (vote_run(m_b, m_w, VXRT_VOTE_BOX)) {
+                if (vote_run(m_b, m_w, VXRT_BATCH_VOTE_BOX)) {
                     if (T.st == ST_BOX)
                         T.phase_box(W);
                     m_b = 0;
                     m_w = __popcll(__ballot(T.st == ST_WALK));
                     m_e = __popcll(__ballot(T.st == ST_END));
                 }
-                if (vote_run(m_e, m_w + m_b, VXRT_VOTE_END)) {
+                if (vote_run(m_e, m_w + m_b, VXRT_BATCH_VOTE_END)) {
                     if (T.st == ST_END)
                         T.phase_end(W);
                 }
