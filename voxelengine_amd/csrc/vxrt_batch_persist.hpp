@@ -18,6 +18,8 @@
 
 namespace vxrt {
 
+// vote thresholds of this kernel: the render kernel's.  Voting 4x / 32x more eagerly -- on the idea that incoherent
+// rays wait for memory, not for instructions -- measured 11 % / 20 % slower: lane efficiency still counts here.
 #ifndef VXRT_BATCH_VOTE_NEXT
 #define VXRT_BATCH_VOTE_NEXT VXRT_VOTE_NEXT
 #endif
