@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("hwc") / "host_wave_check")
     cc = ["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "tools", "hoststub"),
-          "-I" + os.path.join(ROOT, "oracle"), "-o", exe, os.path.join(ROOT, "tools", "host_wave_check.cpp"),
+          "-I" + os.path.join(ROOT, "oracle"), "-o", exe, os.path.join(ROOT, "tests", "tools", "host_wave_check.cpp"),
           "-x", "c", os.path.join(ROOT, "oracle", "vxo_trace.c"), os.path.join(ROOT, "oracle", "vxo_world.c"),
           os.path.join(ROOT, "oracle", "vxo_render.c"), "-lm", "-lpthread", "-w"]
     subprocess.check_call(cc)

@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import voxelengine_amd as vx  # noqa: E402
 from oracle import vxo  # noqa: E402
 from tests import helpers  # noqa: E402
