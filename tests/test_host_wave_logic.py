@@ -1,5 +1,5 @@
 """The wave-level traversal code (voxelengine_amd/csrc/vxrt_wave.hpp) compiled for the HOST with one lane per
-wave (tools/hoststub stands in for the few HIP builtins) and run against the oracle.  This exercises the
+wave (tests/tools/hoststub stands in for the few HIP builtins) and run against the oracle.  This exercises the
 product's traversal logic -- state machine, parking votes, nudges, counters -- on CPU, bit for bit."""
 import os
 import subprocess
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("hwc") / "host_wave_check")
-    cc = ["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "tools", "hoststub"),
+    cc = ["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "tests", "tools", "hoststub"),
           "-I" + os.path.join(ROOT, "oracle"), "-o", exe, os.path.join(ROOT, "tests", "tools", "host_wave_check.cpp"),
           "-x", "c", os.path.join(ROOT, "oracle", "vxo_trace.c"), os.path.join(ROOT, "oracle", "vxo_world.c"),
           os.path.join(ROOT, "oracle", "vxo_render.c"), "-lm", "-lpthread", "-w"]

@@ -1,5 +1,5 @@
 // Debug harness: runs vxrt::trace_wave (one lane) and vxrt::trace_direct on the host against the C oracle.
-// build: g++ -O1 -g -std=c++17 -ffp-contract=off -Itools/hoststub -Ioracle tests/tools/host_wave_check.cpp oracle/vxo_*.c -lm -lpthread
+// build: g++ -O1 -g -std=c++17 -ffp-contract=off -Itests/tools/hoststub -Ioracle tests/tools/host_wave_check.cpp oracle/vxo_*.c -lm -lpthread
 #include "../voxelengine_amd/csrc/vxrt_wave.hpp"
 extern "C" {
 #include "vxo.h"
