@@ -89,8 +89,10 @@ def load() -> C.CDLL:
     except ImportError:
         pass
     path = os.environ.get("VXRT_LIB", _build.LIB_PATH)  # VXRT_LIB: A/B builds of the same library (tools/)
-    if not os.path.exists(path) or os.environ.get("VXRT_REBUILD"):
-        _build.build_lib()
+    if path == _build.LIB_PATH:
+        # staleness check against every source of the library (mtime; runs make only when something is newer), done
+        # here, before this process has touched the GPU, so the make child is harmless
+        _build.build_lib(force=bool(os.environ.get("VXRT_REBUILD")))
     if not os.path.exists(path):
         raise RuntimeError(f"libvxrt.so not found at {path}; run __graft_entry__.build()")
     L = C.CDLL(path)
