@@ -77,6 +77,16 @@ def parse():
 
 def main():
     args = parse()
+    from voxelengine_amd import launcher  # imports neither torch nor HIP
+
+    if args.gpus > 1 and not launcher.under_launcher():
+        # started as a plain program: become the launcher.  N fresh children of this script, one per GPU, are started
+        # BEFORE anything here touches the GPU; rank 0's one JSON line is relayed, a failing rank fails the job.
+        rc, out = launcher.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
+        lines = [ln for ln in out.splitlines() if ln.strip()]
+        if lines:
+            print(lines[-1], flush=True)
+        sys.exit(rc if rc else (0 if lines else 1))
     # stdout carries exactly ONE line, the result JSON.  Native libraries write there too (RCCL prints a version banner
     # to fd 1 when its communicator is created), so fd 1 points at stderr until the line is printed.
     sys.stdout.flush()
@@ -103,8 +113,8 @@ def run(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start bench.py directly (it launches its own ranks) or under "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     rehearse = args.rehearse_on_one_gpu and world > 1
@@ -177,11 +187,17 @@ def run(args):
         pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames, deinterleave,
                                        nbytes=step_bytes)
 
-    def step(i, ev=None):
+    def step(i, ev=None, one_view_launches=False):
         target = frames if not sharded else (pipe.local(i) if pipe else local)
         if ev is not None:
             ev[0].record()
-        ctx.RenderViews(W, H, views_of(i, target), opts())
+        if one_view_launches:  # the reference's call pattern: one RenderScreen-style launch per view
+            o = opts()
+            for v in views_of(i, target):
+                o.frame_number = v["frame_number"]
+                ctx.RenderScreen(W, H, v["fb"], v["origin"], v["fwd"], v["up"], v["right"], o)
+        else:
+            ctx.RenderViews(W, H, views_of(i, target), opts())
         if ev is not None:
             ev[1].record()
         if pipe:
@@ -222,9 +238,30 @@ def run(args):
 
     tot = torch.tensor([float(rays_local), float(bytes_local), float(sum(kernel_ms))], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+    per_rank = [tot.clone()]
     if world > 1:
+        per_rank = [torch.zeros_like(tot) for _ in range(world)]
+        dist.all_gather(per_rank, tot)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    per_rank = [[float(v) for v in t.tolist()] for t in per_rank]
+
+    # the same frames with one view per launch (the reference's RenderScreen call pattern), every rank, same fences
+    dt1 = None
+    if V > 1 and not args.force_gather:
+        ctx.frame_stats()
+        fence()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k, one_view_launches=True)
+        fence()
+        dt1 = time.perf_counter() - t1
+        s1 = ctx.frame_stats()
+        assert s1.total_rays() == rays_local, "ray counts differ between multi-view and single-view launches"
+        t1max = torch.tensor([dt1], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t1max, op=dist.ReduceOp.MAX)
+        dt1 = float(t1max.item())
     rays_total, bytes_total, kernel_ms_total = [float(v) for v in tot.tolist()]
     dt = float(tmax.item())
 
@@ -285,28 +322,26 @@ def run(args):
                                    "note": "all ranks on one GPU over gloo: value is not a measurement" if rehearse
                                    else "one-rank NCCL communicator: exercises the N>1 code path, not a scaling number"}
             ctx.frame_stats()
-        if world == 1 and V > 1 and not args.force_gather:
-            # the same frames with the reference's call pattern, one view per launch (vxrt_render), for comparison
-            torch.cuda.synchronize()
-            ctx.frame_stats()
-            t1 = time.perf_counter()
-            for k in range(args.steps):
-                for v in views_of(args.warmup + k, frames):
-                    ctx.RenderScreen(W, H, v["fb"], v["origin"], v["fwd"], v["up"], v["right"],
-                                     vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,
-                                                      bounce_all_hits=bool(args.bounce_all_hits),
-                                                      bounce_depth=args.bounce_depth, frame_number=v["frame_number"]))
-            torch.cuda.synchronize()
-            dt1 = time.perf_counter() - t1
-            s1 = ctx.frame_stats()
-            assert s1.total_rays() == rays_local, "ray counts differ between multi-view and single-view launches"
+        if dt1 is not None:
             result["one_view_per_launch"] = {
-                "value": round(s1.total_rays() / dt1 / 1e6, 2), "unit": "Mrays/s",
+                "value": round(rays_total / dt1 / 1e6, 2), "unit": "Mrays/s",
                 "ms_per_frame": round(dt1 / (args.steps * V) * 1e3, 4),
                 "roofline_frac": round(bytes_total / dt1 / 1e9 / HBM_PEAK_GBS, 5),
-                "note": "same frames, one vxrt_render launch per frame (the reference's RenderScreen call pattern)"}
-        if args.cpu_baseline == "auto" and world == 1:
-            result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts)
+                "note": "same frames, one vxrt_render launch per frame (the reference's RenderScreen call pattern)"
+                        + ("; every rank launches its strip shard of each frame, the step's shards are gathered as before" if world > 1 else "")}
+        if world > 1:
+            # per-rank roofline of the dominant kernel: algorithmic bytes of the rank's launches / its launch time
+            result["roofline"]["per_rank"] = [
+                {"rank": r, "achieved": round(b / (ms / 1e3) / 1e9, 2), "frac": round(b / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                 "avg_launch_ms": round(ms / args.steps, 4), "rays": int(n)} for r, (n, b, ms) in enumerate(per_rank)]
+        if args.cpu_baseline == "auto" and not args.force_gather:
+            # rank 0 only, after the timed regions (the other ranks wait at the closing barrier); N > 1 times a smaller
+            # sample so that the whole-node run stays short
+            full_opts = lambda: vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,  # noqa: E731
+                                                 bounce_all_hits=bool(args.bounce_all_hits), bounce_depth=args.bounce_depth)
+            nfr = args.cpu_frames if world == 1 else min(args.cpu_frames, V)
+            result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of,
+                                                                    full_opts, nfr)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
@@ -325,7 +360,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts):
+def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts, cpu_frames):
     """The CPU oracle (kind "port": this repo's C restatement of the reference algorithm) timed on the GPU box's
     host cores on a bounded sample of the same workload: the frames of `--cpu-frames / V` steps.  The same frames double
     as a parity gate: the HIP framebuffers of the same steps (same launches as the timed ones) must equal the oracle's
@@ -341,7 +376,7 @@ def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts)
     mismatched = 0
     hit_mismatch = 0
     nframes = 0
-    for s in range(max(1, args.cpu_frames // V)):
+    for s in range(max(1, cpu_frames // V)):
         frames.zero_()
         hits = torch.full((V, H, W), -1, dtype=torch.int64, device=frames.device)
         views = views_of(args.warmup + s, frames, hits)

@@ -212,6 +212,11 @@ int vxrt_deinterleave_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, int3
 int vxrt_trace_batch(vxrt_ctx *ctx, const float *d_origins, const float *d_dirs, uint64_t n, float *d_pos,
                      float *d_normal, int32_t *d_steps, uint8_t *d_hit, int64_t *d_voxel,
                      vxrt_frame_stats *stats_or_null, void *stream);
+/* The device function's first argument, `Raytrace(int maxSteps, ...)` (VolumeRaytracer.cu:354): the budget that is tested
+ * at the head of the two-level loop only (:386).  The batch kernel of the reference passes MAX_STEPS = 2048 (:105), the
+ * secondary rays of calculateColor pass 8 (Renderer.cu:141).  Applies to the following vxrt_trace_batch* calls on this
+ * context; default 2048.  1 <= max_steps <= 2048. */
+int vxrt_set_batch_max_steps(vxrt_ctx *ctx, int32_t max_steps);
 /* host-pointer convenience with the reference's copy-in / copy-out behaviour */
 int vxrt_trace_batch_host(vxrt_ctx *ctx, const float *origins, const float *dirs, uint64_t n, float *pos,
                           float *normal, int32_t *steps, uint8_t *hit, int64_t *voxel,

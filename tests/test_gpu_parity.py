@@ -138,6 +138,66 @@ def test_known_answer_rays_on_gpu(eng, vxo):
     assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == (6, 2, 10)
 
 
+def test_quirk_cases_on_gpu(eng, vxo):
+    """The hand-derived quirk cases of tests/quirk_cases.py (edge padding, exact ties, head-only maxSteps with the bounce
+    rays' budget of 8, double-rounded world-entry box, previous_cell hole, NextCell snap order, region check) through the HIP
+    path: the hand-derived expectations themselves, not just equality with the oracle; all three kernel variants."""
+    from tests import quirk_cases
+    vx, ctx, _ = eng
+    default = ctx.kernel_variant
+    try:
+        for name, case in quirk_cases.all_cases().items():
+            w, o, d = quirk_cases.build_case(vxo, case)
+            _upload(ctx, w)
+            e = case["expect"]
+            ctx.set_batch_max_steps(case["max_steps"])
+            for variant in (2, 0, 1):
+                ctx.set_kernel_variant(variant)
+                r = ctx.Raytrace([o], [d], want_stats=True)
+                assert bool(r["hit"][0]) == e["hit"] and int(r["steps"][0]) == e["steps"], (name, variant)
+                assert r["normal"][0].tolist() == [float(x) for x in e["normal"]], (name, variant)
+                assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == tuple(e["stats"]), (name, variant)
+                if e["hit"]:
+                    assert r["hitPoint"][0].tolist() == [float(np.float32(x)) for x in e["pos"]], (name, variant)
+                    assert int(r["voxel"][0]) == quirk_cases.voxel_index(e["voxel"], case["size"]), (name, variant)
+                else:
+                    assert np.isinf(r["hitPoint"][0]).all() and int(r["voxel"][0]) == -1, (name, variant)
+    finally:
+        ctx.set_batch_max_steps(2048)
+        ctx.set_kernel_variant(default)
+
+
+def test_batch_max_steps_matches_the_oracle(eng, vxo):
+    """Raytrace's maxSteps on whole batches (8 = the secondary rays' budget, Renderer.cu:141), all batch kernels."""
+    import os
+    vx, ctx, _ = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    o, d = helpers.mixed_rays(w.dims, 40000, 33)
+    os.environ["VXRT_WAVES_PER_CU"] = "1"   # a second context whose persistent batch kernel takes batches this small
+    try:
+        small = vx.Context(0)
+    finally:
+        del os.environ["VXRT_WAVES_PER_CU"]
+    try:
+        for c in (ctx, small):
+            _upload(c, w)
+            for ms in (8, 1, 100):
+                c.set_batch_max_steps(ms)
+                got = c.Raytrace(o, d)
+                hit = np.empty(len(o), np.uint8)
+                steps = np.empty(len(o), np.int32)
+                for i in range(0, len(o), 997):   # the oracle's single-ray entry point takes max_steps
+                    r = w.raytrace(o[i], d[i], ms)
+                    assert bool(got["hit"][i]) == r["hit"] and int(got["steps"][i]) == r["steps"], (ms, i)
+            c.set_batch_max_steps(2048)
+            _assert_batch_equal(c.Raytrace(o, d), w.trace_batch(o, d))
+        with pytest.raises(vx.VxrtError):
+            ctx.set_batch_max_steps(0)
+    finally:
+        ctx.set_batch_max_steps(2048)
+        small.close()
+
+
 def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
     vx, ctx, torch = eng
     pos, f, u, r = helpers.camera(cam, w.dims, vxo)

@@ -20,6 +20,7 @@ EXPORTS = [
     "vxrt_set_environment", "vxrt_set_fov", "vxrt_set_ortho_window_size", "vxrt_get_directions",
     "vxrt_render_flags_default", "vxrt_render", "vxrt_render_views", "vxrt_compact_rows", "vxrt_frame_stats_get",
     "vxrt_deinterleave_strips", "vxrt_deinterleave_views", "vxrt_trace_batch", "vxrt_trace_batch_host",
+    "vxrt_set_batch_max_steps",
 ]
 
 
@@ -128,6 +129,7 @@ def load() -> C.CDLL:
                                           C.c_uint64, C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]
     L.vxrt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.POINTER(FrameStats), C.c_void_p]
+    L.vxrt_set_batch_max_steps.argtypes = [C.c_void_p, C.c_int32]
     L.vxrt_trace_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]
     for name in EXPORTS:

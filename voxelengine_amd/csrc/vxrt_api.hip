@@ -60,6 +60,7 @@ struct vxrt_ctx {
     unsigned launch_seq = 0;         // selects the tile counter of the next render launch
     vxrt::ViewArgs* d_views = nullptr;  // per-view arguments of multi-view launches: a ring of slots
     unsigned view_seq = 0;
+    int batch_max_steps = vxrt::kMaxSteps;  // Raytrace's maxSteps for the batch API (vxrt_set_batch_max_steps)
 };
 constexpr unsigned kViewSlots = 16;  // multi-view launches that may be in flight at once on one context
 constexpr unsigned kTileCounterRing = 64;  // render launches that may be in flight at once on one context
@@ -666,6 +667,7 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     B.stats = c->d_stats;
     B.ticket = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
     B.persistent_waves = c->persistent_waves;
+    B.max_steps = c->batch_max_steps;
     unsigned int* d_dbg = nullptr;
     if (stats && getenv("VXRT_DEBUG_TRACE")) {  // development: dump the wave loop's view of ray 0
         VX_HIP(hipMalloc((void**)&d_dbg, 400 * 12 * 4));
@@ -695,6 +697,14 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
         }
         return vxrt_frame_stats_get(c, stats);
     }
+    return VXRT_OK;
+}
+
+int vxrt_set_batch_max_steps(vxrt_ctx* c, int32_t max_steps)
+{
+    if (!c || max_steps < 1 || max_steps > vxrt::kMaxSteps)
+        return fail(VXRT_ERR_INVALID, "max_steps must be in [1, 2048]");
+    c->batch_max_steps = max_steps;
     return VXRT_OK;
 }
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_batch_persist(BatchArgs B)
                 const unsigned long long j = my_ray;
                 const f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
                 const f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
-                T.begin_ray(W, o, d, kMaxSteps);
+                T.begin_ray(W, o, d, B.max_steps);
             }
             if (drained && T.st == ST_DONE && my_ray == kNone)
                 T.st = ST_IDLE;

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_trace_batch(BatchArgs B)
         f3 o = mk3(B.origins[3 * i], B.origins[3 * i + 1], B.origins[3 * i + 2]);
         f3 d = mk3(B.dirs[3 * i], B.dirs[3 * i + 1], B.dirs[3 * i + 2]);
         TraceResult t;
-        trace_direct(B.W, kMaxSteps, o, d, t, cnt);
+        trace_direct(B.W, B.max_steps, o, d, t, cnt);
         rays = 1;
         hits = t.hit ? 1 : 0;
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);  // dispatch, VolumeRaytracer.cu:105-113
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
     f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
     f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
     TraceResult t;
-    trace_wave<STATS, true>(B.W, kMaxSteps, live, o, d, t, cnt, (STATS && i == 0) ? B.dbg_trace : nullptr);
+    trace_wave<STATS, true>(B.W, B.max_steps, live, o, d, t, cnt, (STATS && i == 0) ? B.dbg_trace : nullptr);
     if (live) {
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
         B.pos[3 * i] = p.x;

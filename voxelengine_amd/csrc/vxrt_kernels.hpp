@@ -89,6 +89,7 @@ struct BatchArgs {
     unsigned int* dbg_trace;  // development: per-iteration state of ray 0 (probe-counting variant only), or NULL
     unsigned int* ticket;     // persistent batch kernel: next 64-ray ticket of the queue (zeroed per launch), or NULL
     unsigned int persistent_waves;
+    int max_steps;            // Raytrace's maxSteps (VolumeRaytracer.cu:354,386); kMaxSteps unless the caller lowered it
 };
 
 }  // namespace vxrt

@@ -222,6 +222,11 @@ class Context:
                                                 int(fb_stride_bytes), _stream(stream)))
 
     # ---- batch -----------------------------------------------------------------------------------
+    def set_batch_max_steps(self, max_steps: int) -> None:
+        """``maxSteps`` of the device function ``Raytrace`` for the following batch calls (default 2048; the
+        reference's secondary rays use 8, VoxelRT/Renderer.cu:141)."""
+        N.check(self._L.vxrt_set_batch_max_steps(self._h, int(max_steps)))
+
     def Raytrace(self, origins, dirs, want_stats: bool = False):
         """VoxelRaytracer3D::Raytrace (VoxelRT/VolumeRaytracer.cu:574-618) on host arrays: copy in, trace,
         copy out.  Returns the reference's fields (hitPoint=+inf on a miss, normal, steps, valid, distance)
