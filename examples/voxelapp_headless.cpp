@@ -4,14 +4,23 @@
 // is a scripted path instead of keyboard/mouse input; the last frame is written as raw BGRA and as a PPM.
 //
 //   voxelapp_headless [world_edge=256] [frames=2] [out_prefix=frame] [width=320] [height=180] [shaded=0]
-//                     [camera_path_file] [dump_every_frame=0] [views_per_launch=1]
+//                     [camera_path_file] [dump_every_frame=0] [views_per_launch=1] [frames_in_flight=1] [device_world=XxYxZ]
 //
+// shaded: 0 = the checked-in debug view, 1 = shaded with shadow + 1 bounce sample, checkerboard on, 2 = the same with the
+// checkerboard off (whole frames).  frames_in_flight=2 renders through Graphics::RenderScreenAsync / WaitFrame: frame k+1 is
+// launched before frame k is copied to the host, on two alternating device buffers (use shaded=2: under checkerboard a
+// frame needs its predecessor's buffer).  device_world=8192x512x8192 builds the brickmap on the device in one step
+// (VoxelRaytracer3D::BuildProceduralWorld) instead of CreateVoxels + GenerateLowresVoxelBuffer, whose dense bit array
+// the reference cannot index beyond 2^32 voxels; `world_edge` then only scales the default camera.  A '-' skips
+// camera_path_file.  The run ends with the rays traced and the Mrays/s over the frame loop.
+
 // camera_path_file replaces the fixed camera: one frame per line, "x y z eulerX eulerY eulerZ" (voxels, radians;
 // '#' starts a comment); `frames` is then the number of lines.  With dump_every_frame=1 each frame is also written
 // as <out_prefix>_NNNN.ppm (under checkerboard rendering a frame keeps the other half of the previous one).
 // views_per_launch > 1 renders that many poses per launch through Graphics::RenderScreens (no checkerboard then).
 #include "../include/GPUDDA/Renderer.h"
 #include "../include/GPUDDA/VoxelWorldBuilder.h"
+#include "../include/vxrt.h"
 
 #include <hip/hip_runtime_api.h>
 
@@ -34,9 +43,16 @@ int main(int argc, char** argv)
     const std::string prefix = argc > 3 ? argv[3] : "frame";
     const uint32_t width = argc > 4 ? (uint32_t)atoi(argv[4]) : 320u, height = argc > 5 ? (uint32_t)atoi(argv[5]) : 180u;
     const bool shaded = argc > 6 && atoi(argv[6]) != 0;
-    const std::string path_file = argc > 7 ? argv[7] : "";
+    const int shade_mode = argc > 6 ? atoi(argv[6]) : 0;
+    const std::string path_file = (argc > 7 && std::string(argv[7]) != "-") ? argv[7] : "";
     const bool dump_all = argc > 8 && atoi(argv[8]) != 0;
     const int batch = argc > 9 ? atoi(argv[9]) : 1;
+    const int in_flight = argc > 10 ? atoi(argv[10]) : 1;
+    unsigned wx = 0, wy = 0, wz = 0;
+    if (argc > 11 && std::sscanf(argv[11], "%ux%ux%u", &wx, &wy, &wz) != 3) {
+        std::cerr << "device_world must look like 8192x512x8192" << std::endl;
+        return 2;
+    }
 
     struct Pose {
         float3 pos, euler;
@@ -64,27 +80,33 @@ int main(int argc, char** argv)
     }
 
     int factor = 32;
-    auto t0 = std::chrono::high_resolution_clock::now();
-    auto buffer = CreateVoxels(make_uint3(edge, edge, edge));
-    auto t1 = std::chrono::high_resolution_clock::now();
-    std::cout << "Voxel generation time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
-
-    auto buffers = GenerateLowresVoxelBuffer(buffer, factor);
-    auto t2 = std::chrono::high_resolution_clock::now();
-    std::cout << "Buffer generation time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms" << std::endl;
-    delete[] buffer.grid.Raw();
-
     VoxelRaytracer3D* raytracer = new VoxelRaytracer3D(1);
-    auto low_res_buffer = std::get<0>(buffers);
-    auto low_res_grid_data = std::get<1>(buffers);
-    auto bounds = std::get<2>(buffers);
-    auto count = (size_t)low_res_buffer.dimensions[0] * low_res_buffer.dimensions[1] * low_res_buffer.dimensions[2];
-    raytracer->UploadVoxelBuffer(low_res_buffer);
-    raytracer->UploadVoxelBufferDatas(low_res_grid_data, count);
-    raytracer->UploadVoxelBufferDataBounds(bounds, count);
-    raytracer->SetFactor(factor);
+    auto t0 = std::chrono::high_resolution_clock::now();
+    if (wx) {
+        raytracer->BuildProceduralWorld(make_uint3(wx, wy, wz), factor);
+        auto t1 = std::chrono::high_resolution_clock::now();
+        std::cout << "World built on the device: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
+    } else {
+        auto buffer = CreateVoxels(make_uint3(edge, edge, edge));
+        auto t1 = std::chrono::high_resolution_clock::now();
+        std::cout << "Voxel generation time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms" << std::endl;
 
-    float3 cam_pos = make_float3(edge * 0.25f, edge * 0.9f, edge * 0.25f);
+        auto buffers = GenerateLowresVoxelBuffer(buffer, factor);
+        auto t2 = std::chrono::high_resolution_clock::now();
+        std::cout << "Buffer generation time: " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms" << std::endl;
+        delete[] buffer.grid.Raw();
+
+        auto low_res_buffer = std::get<0>(buffers);
+        auto low_res_grid_data = std::get<1>(buffers);
+        auto bounds = std::get<2>(buffers);
+        auto count = (size_t)low_res_buffer.dimensions[0] * low_res_buffer.dimensions[1] * low_res_buffer.dimensions[2];
+        raytracer->UploadVoxelBuffer(low_res_buffer);
+        raytracer->UploadVoxelBufferDatas(low_res_grid_data, count);
+        raytracer->UploadVoxelBufferDataBounds(bounds, count);
+        raytracer->SetFactor(factor);
+    }
+
+    float3 cam_pos = wx ? make_float3(wx * 0.5f, wy * 0.9f, wz * 0.5f) : make_float3(edge * 0.25f, edge * 0.9f, edge * 0.25f);
     float3 cam_up, cam_right, cam_forward;
     float3 cam_eular = make_float3(-0.45f, 0.7f, 0.0f);
 
@@ -101,6 +123,7 @@ int main(int argc, char** argv)
         s.DebugView = false;
         s.ShadowRay = true;
         s.BounceSamples = 1;
+        s.Checkerboard = shade_mode != 2;
         SetRenderSwitches(s);
     }
 
@@ -121,6 +144,49 @@ int main(int argc, char** argv)
 
     double avgFrameTime = 0.0;
     const int nframes = path.empty() ? frames : (int)path.size();
+    vxrt_frame_stats rays_before{};
+    (void)vxrt_frame_stats_get(raytracer->Context(), &rays_before);  // start the ray counters of the frame loop from zero
+    const auto loop0 = std::chrono::high_resolution_clock::now();
+    double dump_ms = 0.0;
+    auto timed_dump = [&](int i) {
+        if (!dump_all)
+            return;
+        const auto d0 = std::chrono::high_resolution_clock::now();
+        char name[32];
+        std::snprintf(name, sizeof(name), "_%04d.ppm", i);
+        write_ppm(prefix + name);
+        dump_ms += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - d0).count() / 1000.0;
+    };
+    if (batch <= 1 && in_flight >= 2) {
+        // Two frames in flight (Graphics::RenderScreenAsync): launch frame i, THEN wait for frame i-1 and copy it to the host
+        // -- the per-frame sequence of VoxelApp/main.cu:165-167 shifted by one frame.  The camera of frame i may depend on
+        // anything the host knows when it launches it (input, frame i-2's pixels); nothing is batched ahead.
+        void* d_ring[2] = {d_pixels, nullptr};
+        if (hipMalloc(&d_ring[1], (size_t)width * height * sizeof(BGRA8888)) != hipSuccess)
+            return 1;
+        (void)hipMemset(d_ring[1], 255, (size_t)width * height * sizeof(BGRA8888));
+        FrameTicket tickets[2] = {0, 0};
+        for (int i = 0; i <= nframes; ++i) {
+            auto f0 = std::chrono::high_resolution_clock::now();
+            if (i < nframes) {
+                if (!path.empty()) {
+                    cam_pos = path[(size_t)i].pos;
+                    cam_eular = path[(size_t)i].euler;
+                }
+                GetDirections(cam_eular, &cam_forward, &cam_up, &cam_right);
+                tickets[i % 2] = RenderScreenAsync(raytracer, width, height, d_ring[i % 2], cam_pos, cam_forward, cam_up, cam_right);
+            }
+            if (i > 0) {
+                WaitFrame(tickets[(i - 1) % 2]);
+                (void)hipMemcpy(pixels.data(), d_ring[(i - 1) % 2], pixels.size() * sizeof(BGRA8888), hipMemcpyDeviceToHost);
+                timed_dump(i - 1);
+            }
+            auto f1 = std::chrono::high_resolution_clock::now();
+            double td = std::chrono::duration_cast<std::chrono::microseconds>(f1 - f0).count() / 1000.0;
+            avgFrameTime = i == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
+        }
+        (void)hipFree(d_ring[1]);
+    }
     if (batch > 1) {
         // several poses per launch (Graphics::RenderScreens): every view has its own framebuffer, so this mode runs
         // without the checkerboard's frame-to-frame history
@@ -152,17 +218,13 @@ int main(int argc, char** argv)
             avgFrameTime = first == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
             for (int j = 0; j < n; ++j) {
                 (void)hipMemcpy(pixels.data(), d_views[(size_t)j], pixels.size() * sizeof(BGRA8888), hipMemcpyDeviceToHost);
-                if (dump_all) {
-                    char name[32];
-                    std::snprintf(name, sizeof(name), "_%04d.ppm", first + j);
-                    write_ppm(prefix + name);
-                }
+                timed_dump(first + j);
             }
         }
         for (auto p : d_views)
             (void)hipFree(p);
     }
-    for (int i = 0; batch <= 1 && i < nframes; ++i) {
+    for (int i = 0; batch <= 1 && in_flight < 2 && i < nframes; ++i) {
         if (!path.empty()) {
             cam_pos = path[(size_t)i].pos;
             cam_eular = path[(size_t)i].euler;
@@ -174,13 +236,17 @@ int main(int argc, char** argv)
         auto f1 = std::chrono::high_resolution_clock::now();
         double td = std::chrono::duration_cast<std::chrono::microseconds>(f1 - f0).count() / 1000.0;
         avgFrameTime = i == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
-        if (dump_all) {
-            char name[32];
-            std::snprintf(name, sizeof(name), "_%04d.ppm", i);
-            write_ppm(prefix + name);
-        }
+        timed_dump(i);
     }
     std::cout << "Avg FPS: " << 1000.0 / avgFrameTime << std::endl;
+    {
+        vxrt_frame_stats st{};
+        (void)vxrt_frame_stats_get(raytracer->Context(), &st);  // synchronises the device
+        const double loop_ms = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - loop0).count() / 1000.0 - dump_ms;
+        const unsigned long long rays = st.primary_rays + st.shadow_rays + st.bounce_rays;
+        std::printf("Frame loop: %d frames, %llu rays in %.3f ms (device->host copy of every frame included) = %.1f Mrays/s\n", nframes, rays,
+                    loop_ms, loop_ms > 0 ? rays / loop_ms / 1e3 : 0.0);
+    }
 
     std::ofstream raw(prefix + ".bgra", std::ios::binary);
     raw.write(reinterpret_cast<const char*>(pixels.data()), (std::streamsize)(pixels.size() * sizeof(BGRA8888)));

@@ -50,5 +50,19 @@ struct ScreenView {
 };
 void RenderScreens(VoxelRaytracer3D* rt, uint32_t screen_width, uint32_t screen_height, const ScreenView* views, uint32_t count);
 
+// This build's addition for interactive callers (their next camera depends on input, so they cannot pre-batch views):
+// RenderScreen WITHOUT the closing device synchronisation.  Frames alternate between two internal streams, so up to two
+// frames are in flight and the wavefronts of frame k+1 fill the SIMD slots that the last, longest rays of frame k leave
+// (a single 1080p frame keeps the GPU full for only ~70 % of its launch; measured 3.3 -> 4.6 Grays/s).  The frame is exactly
+// the frame RenderScreen produces.  Give consecutive frames different device buffers; WaitFrame(ticket) returns once that
+// frame is complete (then the device->host copy of VoxelApp/main.cu:167 may read it).  A third unfinished frame makes
+// RenderScreenAsync wait for the oldest one first.
+typedef uint64_t FrameTicket;
+FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t screen_width, uint32_t screen_height, void* d_screen_texture,
+                              float3 origin, float3 camera_fwd, float3 camera_up, float3 camera_right);
+void WaitFrame(FrameTicket ticket);
+// the stream a ticket's frame was rendered on (a hipStream_t), e.g. to enqueue the device->host copy behind it
+void* FrameStream(FrameTicket ticket);
+
 }  // namespace Graphics
 }  // namespace GPUDDA

@@ -178,7 +178,9 @@ int vxrt_render(vxrt_ctx *ctx, uint32_t width, uint32_t height, void *d_fb, cons
  * one-view launches at 1080p).  Every view is exactly the frame vxrt_render would produce for the same camera,
  * frame number and flags.  `flags` applies to all views; its frame_number, d_color_aov, d_hit_aov and d_tile_order
  * are ignored (per-view members below).  1 <= n_views <= 16.  Launches issued on different streams may also be in
- * flight together (up to 16 multi-view, 64 single-view per context); host calls on a context stay serialised. */
+ * flight together: up to 64 launches (16 of them multi-view) per context share no state; the call that would exceed that
+ * waits on the host for the oldest launch to finish before it reuses its queue head / view slot.  (Inside a stream capture
+ * nothing can be waited for: the capturing caller keeps within those limits.)  Host calls on a context stay serialised. */
 typedef struct vxrt_view {
     void *d_fb;             /* W*H*4 bytes BGRA8 (or the compact size) */
     float origin[3], fwd[3], up[3], right[3];
@@ -190,8 +192,9 @@ int vxrt_render_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, uint32_t n
                       const vxrt_render_flags *flags);
 /* number of frame rows owned by a shard, = rows of its compact buffer */
 uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_count, int32_t strip_index);
-/* counters accumulated by the vxrt_render calls on this context since the previous read;
- * synchronises the device, then clears them */
+/* counters accumulated by the launches on this context since the previous read, whatever their streams; synchronises
+ * the device (every stream).  The device-side counters only grow: "since the previous read" is a host-side snapshot, so a
+ * read never clears memory that a running kernel adds to. */
 int vxrt_frame_stats_get(vxrt_ctx *ctx, vxrt_frame_stats *out);
 /* scatter `strip_count` compact shard buffers (laid out back to back, shard-major, each padded to
  * `shard_stride_bytes`) into a full W*H BGRA8 frame on the device; used by the root after the gather. */

@@ -97,3 +97,36 @@ def test_headless_voxelapp_renders_several_poses_per_launch(vxo, tmp_path):
         head = b"P6\n%d %d\n255\n" % (W, H)
         rgb = np.frombuffer(raw[len(head):], np.uint8).reshape(H, W, 3)
         assert np.array_equal(rgb, want[:, :, [2, 1, 0]]), frame
+
+
+@pytest.mark.gpu
+def test_two_frames_in_flight_equal_the_synchronous_frames(vxo, tmp_path):
+    """Graphics::RenderScreenAsync / WaitFrame (this build's addition for interactive callers): a five-pose fly-through
+    rendered with two frames in flight gives, frame by frame, the bytes of the synchronous RenderScreen loop, and both
+    equal the oracle.  The world is built on the device in one step (device_world argument)."""
+    assert os.path.exists(EXE), "run __graft_entry__.build() first"
+    W, H = 200, 120
+    poses = [((64.0, 230.0, 64.0), (-0.45, 0.7, 0.0)), ((70.5, 228.0, 66.0), (-0.5, 0.8, 0.0)),
+             ((80.0, 220.25, 72.0), (-0.6, 1.0, 0.0)), ((90.0, 215.0, 80.0), (-0.7, 1.2, 0.0)),
+             ((100.0, 240.0, 90.0), (-1.2, 1.4, 0.0))]
+    path = tmp_path / "path.txt"
+    path.write_text("".join("%r %r %r %r %r %r\n" % (*p, *e) for p, e in poses))
+    runs = {}
+    for flight in (1, 2):
+        prefix = str(tmp_path / ("f%d" % flight))
+        out = subprocess.run([EXE, "256", "0", prefix, str(W), str(H), "2", str(path), "1", "1", str(flight), "256x256x256"],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr
+        assert "World built on the device" in out.stdout and "Mrays/s" in out.stdout
+        runs[flight] = [open("%s_%04d.ppm" % (prefix, i), "rb").read() for i in range(len(poses))]
+        assert np.array_equal(np.fromfile(prefix + ".bgra", np.uint8), np.fromfile(str(tmp_path / "f1.bgra"), np.uint8))
+    assert runs[1] == runs[2]
+    w = vxo.World.generate(vxo.GEN_PERLIN_REF, 256, 256, 256, 32, nthreads=16)
+    head = b"P6\n%d %d\n255\n" % (W, H)
+    for frame, (pos, euler) in enumerate(poses):
+        f, u, r = vxo.get_directions(euler)
+        p = vxo.make_params(W, H, tuple(np.float32(v) for v in pos), f, u, r, frame_number=frame, mode=vxo.MODE_SHADED,
+                            shadow=1, bounce_samples=1)
+        want = w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"]
+        rgb = np.frombuffer(runs[2][frame][len(head):], np.uint8).reshape(H, W, 3)
+        assert np.array_equal(rgb, want[:, :, [2, 1, 0]]), frame

@@ -198,6 +198,52 @@ def test_batch_max_steps_matches_the_oracle(eng, vxo):
         small.close()
 
 
+def test_eighty_launches_in_flight_over_four_streams(eng, vxo):
+    """More launches in flight than the context has queue heads (64 single-view, 16 multi-view): launch 65 waits for launch 1
+    instead of sharing its tile counter (vxrt_api.hip ring_acquire).  80 single-view launches and 20 multi-view launches
+    over 4 streams, no synchronisation in between; every frame must be the frame a lone launch renders, and the ray
+    counters must add up."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+    _upload(ctx, w)
+    W, H = 200, 120
+    cams = [helpers.camera(c, w.dims, vxo) for c in "ABCD"]
+    inv = float(np.float32(1.0) / np.sqrt(np.float32(3.0)))
+    ctx.SetEnvironment((inv, inv, inv), (2, 2, 2), (0.5, 0.5, 0.5))
+    ctx.SetFOV(90.0)
+    base = dict(shadow=True, bounce_samples=1)
+    ref, rays_ref = [], []
+    for j, (pos, f, u, r) in enumerate(cams):     # one at a time
+        fb = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        ctx.frame_stats()
+        ctx.RenderScreen(W, H, fb, pos, f, u, r, vx.RenderOptions(frame_number=j + 1, **base))
+        rays_ref.append(ctx.frame_stats().total_rays())
+        ref.append(fb.clone())
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    fbs = torch.zeros((80, H, W, 4), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    ctx.frame_stats()
+    for i in range(80):
+        pos, f, u, r = cams[i % 4]
+        with torch.cuda.stream(streams[i % 4]):
+            ctx.RenderScreen(W, H, fbs[i], pos, f, u, r, vx.RenderOptions(frame_number=i % 4 + 1, **base))
+    torch.cuda.synchronize()
+    st = ctx.frame_stats()
+    assert st.total_rays() == 20 * sum(rays_ref)
+    for i in range(80):
+        assert torch.equal(fbs[i], ref[i % 4]), i
+    mv = torch.zeros((20, 4, H, W, 4), dtype=torch.uint8, device="cuda")
+    for k in range(20):
+        with torch.cuda.stream(streams[k % 4]):
+            ctx.RenderViews(W, H, [dict(fb=mv[k, j], origin=c[0], fwd=c[1], up=c[2], right=c[3], frame_number=j + 1)
+                                   for j, c in enumerate(cams)], vx.RenderOptions(**base))
+    torch.cuda.synchronize()
+    assert ctx.frame_stats().total_rays() == 20 * sum(rays_ref)
+    for k in range(20):
+        for j in range(4):
+            assert torch.equal(mv[k, j], ref[j]), (k, j)
+
+
 def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
     vx, ctx, torch = eng
     pos, f, u, r = helpers.camera(cam, w.dims, vxo)

@@ -8,18 +8,19 @@ import pytest
 
 from tests import helpers
 
-HEADER = "<8sIIiiiiQQQQQQQQQ"   # magic, version, header bytes, factor, cdims[3], ncells, nslots, 3 sizes, 3 sums, reserved
+HEADER = "<8sIIiiiiQQQQQQQQQQQ"   # magic, version, header bytes, factor, cdims[3], ncells, nslots, 3 sizes, 3 sums, 3 sums of running sums
+HEADER_BYTES = 120
 
 
-def _header(factor=8, cdims=(8, 8, 8), nslots=3, version=1, magic=b"VXBRKMAP", sizes=None):
+def _header(factor=8, cdims=(8, 8, 8), nslots=3, version=2, magic=b"VXBRKMAP", sizes=None):
     ncells = cdims[0] * cdims[1] * cdims[2]
     bw = factor ** 3 // 32
     sizes = sizes or (((ncells + 31) // 32) * 4, ncells * 8, nslots * bw * 4)
-    return struct.pack(HEADER, magic, version, struct.calcsize(HEADER), factor, *cdims, ncells, nslots, *sizes, 0, 0, 0, 0)
+    return struct.pack(HEADER, magic, version, struct.calcsize(HEADER), factor, *cdims, ncells, nslots, *sizes, 0, 0, 0, 0, 0, 0)
 
 
-def test_header_is_104_bytes():
-    assert struct.calcsize(HEADER) == 104
+def test_header_is_120_bytes():
+    assert struct.calcsize(HEADER) == HEADER_BYTES
 
 
 def test_file_info_reads_a_header_and_rejects_bad_ones(tmp_path):
@@ -31,7 +32,7 @@ def test_file_info_reads_a_header_and_rejects_bad_ones(tmp_path):
     assert info.hbm_bytes == 16 * 8 * 24 // 8 + 16 * 8 * 24 * 8 + 5 * 512
     cases = {
         "magic": _header(magic=b"NOTAMAP!"),
-        "version": _header(version=2),
+        "version": _header(version=1),             # the additive-checksum format of round 1 is not read any more
         "factor": _header(factor=12),
         "dims": _header(cdims=(8, 4, 8)),            # not a multiple of 8
         "sizes": _header(sizes=(64, 4096, 999)),     # pool size does not match nslots
@@ -75,7 +76,7 @@ def test_save_load_round_trip(eng, vxo, tmp_path):
     ctx.save_world(path)
     info = vx.world_file_info(path)
     assert (info.factor, tuple(info.cdims), info.nslots) == (16, tuple(w.cdims), w.pool.size // 128)
-    assert os.path.getsize(path) == 104 + info.hbm_bytes
+    assert os.path.getsize(path) == HEADER_BYTES + info.hbm_bytes
 
     other = vx.Context(0)
     try:
@@ -100,7 +101,7 @@ def test_damaged_files_are_rejected_and_leave_no_world(eng, vxo, tmp_path):
     ctx.save_world(path)
     blob = bytearray(open(path, "rb").read())
     ncells = int(np.prod(w.cdims))
-    meta_off = 104 + ((ncells + 31) // 32) * 4
+    meta_off = HEADER_BYTES + ((ncells + 31) // 32) * 4
     occupied = int(np.flatnonzero(w.brick_slot != 0xFFFFFFFF)[0])
     damaged = {}
     flipped = bytearray(blob)
@@ -110,6 +111,26 @@ def test_damaged_files_are_rejected_and_leave_no_world(eng, vxo, tmp_path):
     wild = bytearray(blob)
     wild[meta_off + occupied * 8:meta_off + occupied * 8 + 4] = struct.pack("<I", 0x7FFFFFFF)   # slot outside the pool
     damaged["wild slot"] = bytes(wild)
+    # two different pool words swapped: an additive checksum cannot see it, the sum of running sums does
+    pool_off = meta_off + ncells * 8
+    words = np.frombuffer(bytes(blob[pool_off:]), np.uint32).copy()
+    i = int(np.flatnonzero(words != words[0])[0])
+    words[0], words[i] = words[i], words[0]
+    damaged["swapped words"] = bytes(blob[:pool_off]) + words.tobytes()
+    # tight extents outside the brick / min above max in an occupied cell, with the checksums of the header recomputed
+    # so that only the validation of the fields can catch them
+    for label, ext in (("extent beyond brick", 31 << 15), ("min above max", (5 << 0) | (2 << 15))):
+        bad = bytearray(blob)
+        off = meta_off + occupied * 8 + 4
+        bad[off:off + 4] = struct.pack("<I", ext)
+        meta = np.frombuffer(bytes(bad[meta_off:pool_off]), np.uint32).astype(np.uint64)
+        a = int(meta.sum() % (1 << 64))
+        run = np.cumsum(meta, dtype=np.uint64)
+        b = int(run.sum(dtype=np.uint64))
+        hdr = list(struct.unpack(HEADER, bytes(bad[:HEADER_BYTES])))
+        hdr[13], hdr[16] = a, b   # sum[1], sum2[1]
+        bad[:HEADER_BYTES] = struct.pack(HEADER, *hdr)
+        damaged[label] = bytes(bad)
     other = vx.Context(0)
     try:
         for name, data in damaged.items():

@@ -349,6 +349,62 @@ void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_t
     ok(vxrt_synchronize(c), "vxrt_synchronize");  // RenderScreen returns with the frame finished (Renderer.cu:327)
 }
 
+// ---- two frames in flight (RenderScreenAsync / WaitFrame) ---------------------------------------------------------
+namespace {
+struct FrameSlots {
+    hipStream_t stream[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    FrameTicket issued = 0;  // tickets count from 1; ticket t uses slot t % 2
+    ~FrameSlots()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (done[i]) (void)hipEventDestroy(done[i]);
+            if (stream[i]) (void)hipStreamDestroy(stream[i]);
+        }
+    }
+};
+FrameSlots g_frames;
+
+void hip_ok(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) {
+        std::fprintf(stderr, "GPUDDA: %s: %s\n", what, hipGetErrorString(e));
+        std::exit(EXIT_FAILURE);  // CUDA_SAFE_CALL's behaviour (Renderer.cuh:15-23)
+    }
+}
+}  // namespace
+
+FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_texture, float3 origin, float3 fwd,
+                              float3 up, float3 right)
+{
+    vxrt_render_flags fl;
+    vxrt_ctx* c = prepare_launch(rt, fl);
+    const FrameTicket t = ++g_frames.issued;
+    const int s = (int)(t % 2);
+    if (!g_frames.stream[s]) {
+        // non-blocking: the two streams overlap each other and do not join the caller's default stream
+        hip_ok(hipStreamCreateWithFlags(&g_frames.stream[s], hipStreamNonBlocking), "hipStreamCreateWithFlags");
+        hip_ok(hipEventCreateWithFlags(&g_frames.done[s], hipEventDisableTiming), "hipEventCreateWithFlags");
+    } else {
+        hip_ok(hipEventSynchronize(g_frames.done[s]), "hipEventSynchronize");  // frame t-2 used this slot
+    }
+    fl.stream = g_frames.stream[s];
+    const float o[3] = {origin.x, origin.y, origin.z}, f[3] = {fwd.x, fwd.y, fwd.z}, u[3] = {up.x, up.y, up.z},
+                r[3] = {right.x, right.y, right.z};
+    ok(vxrt_render(c, w, h, d_screen_texture, o, f, u, r, &fl), "vxrt_render");
+    hip_ok(hipEventRecord(g_frames.done[s], g_frames.stream[s]), "hipEventRecord");
+    return t;
+}
+
+void WaitFrame(FrameTicket t)
+{
+    if (t == 0 || t > g_frames.issued || t + 2 <= g_frames.issued)
+        return;  // never issued, or older than the two frames that can be in flight: already complete
+    hip_ok(hipEventSynchronize(g_frames.done[t % 2]), "hipEventSynchronize");
+}
+
+void* FrameStream(FrameTicket t) { return g_frames.stream[t % 2]; }
+
 void RenderScreens(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, const ScreenView* views, uint32_t count)
 {
     vxrt_render_flags fl;

@@ -5,6 +5,7 @@
 #include "vxrt_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -15,8 +16,8 @@
 #include <vector>
 
 namespace vxrt {
-void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
-void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
+hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
                          uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream, uint32_t n_views = 1,
                          unsigned long long view_stride_bytes = 0, unsigned long long fb_stride_bytes = 0);
@@ -57,13 +58,23 @@ struct vxrt_ctx {
     int kernel_variant = 2;          // render: 2 = persistent waves (default), 0 = wave state machine, 1 = straightforward
     unsigned persistent_waves = 4096;
     unsigned long long* d_stats = nullptr;
-    unsigned launch_seq = 0;         // selects the tile counter of the next render launch
-    vxrt::ViewArgs* d_views = nullptr;  // per-view arguments of multi-view launches: a ring of slots
-    unsigned view_seq = 0;
+    // Counters only ever grow on the device (atomics from any stream); "read and clear" is a host-side snapshot that the
+    // next read subtracts, so nothing clears device memory under running kernels.
+    unsigned long long stats_base[vxrt::kStatCount] = {};
+    // Rings: queue heads (render tile counters / batch tickets) and per-view argument slots of multi-view launches.  A ring
+    // entry carries the event of the launch that used it last; taking an entry that is still in flight waits for that launch
+    // (launch 65 of 64 in flight, multi-view launch 17 of 16), so an entry is never shared by two live launches.
+    std::atomic<unsigned> launch_seq{0};
+    hipEvent_t counter_busy[64] = {};
+    vxrt::ViewArgs* d_views = nullptr;
+    std::atomic<unsigned> view_seq{0};
+    hipEvent_t views_busy[16] = {};
     int batch_max_steps = vxrt::kMaxSteps;  // Raytrace's maxSteps for the batch API (vxrt_set_batch_max_steps)
 };
 constexpr unsigned kViewSlots = 16;  // multi-view launches that may be in flight at once on one context
 constexpr unsigned kTileCounterRing = 64;  // render launches that may be in flight at once on one context
+static_assert(kTileCounterRing == sizeof(vxrt_ctx::counter_busy) / sizeof(hipEvent_t), "ring size");
+static_assert(kViewSlots == sizeof(vxrt_ctx::views_busy) / sizeof(hipEvent_t), "ring size");
 
 namespace vxrt {
 
@@ -144,6 +155,36 @@ int adopt_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t nslots, uint3
 }
 
 int set_error(int code, const char* msg) { return fail(code, msg); }
+void abandon_world(vxrt_ctx* c) { free_world(c); }
+
+// Take ring entry `i`: if the launch that used it last has not finished, wait for it (the documented in-flight limits are
+// enforced here instead of silently sharing a queue head).  Inside a stream capture nothing can be waited for or
+// recorded: the capturing caller keeps within the limits itself.
+static hipError_t ring_acquire(hipEvent_t& ev, hipStream_t stream, bool& capturing)
+{
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (stream && hipStreamIsCapturing(stream, &cs) != hipSuccess)
+        (void)hipGetLastError();
+    capturing = cs != hipStreamCaptureStatusNone;
+    if (capturing || !ev)
+        return hipSuccess;
+    hipError_t e = hipEventQuery(ev);
+    if (e == hipErrorNotReady)
+        e = hipEventSynchronize(ev);
+    return e;
+}
+
+static hipError_t ring_release(hipEvent_t& ev, hipStream_t stream, bool capturing)
+{
+    if (capturing)
+        return hipSuccess;
+    if (!ev) {
+        hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess)
+            return e;
+    }
+    return hipEventRecord(ev, stream);
+}
 
 // Default hand-out order of the persistent kernel's tile queue: expected-longest ray chains first, so that what is
 // still in flight when the queue runs dry is cheap.  The cost proxy needs the camera only: the elevation of the
@@ -233,6 +274,10 @@ int vxrt_destroy(vxrt_ctx* c)
     vxrt::free_world(c);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_views) (void)hipFree(c->d_views);
+    for (hipEvent_t& e : c->counter_busy)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t& e : c->views_busy)
+        if (e) (void)hipEventDestroy(e);
     delete c;
     return VXRT_OK;
 }
@@ -515,9 +560,13 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
             A.row_order_n = 0;
             if (schedule && !A.tile_order)
                 vxrt::schedule_tile_rows(A, A.fwd, A.up, A.row_order, A.row_order_n);
-            A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
-            vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
+            const unsigned slot = c->launch_seq.fetch_add(1u) % kTileCounterRing;
+            bool capturing = false;
+            VX_HIP(vxrt::ring_acquire(c->counter_busy[slot], stream, capturing));
+            A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + slot;
+            VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
             VX_HIP(hipGetLastError());
+            VX_HIP(vxrt::ring_release(c->counter_busy[slot], stream, capturing));
         }
         return VXRT_OK;
     }
@@ -540,13 +589,19 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
         if (schedule)
             vxrt::schedule_tile_rows(A, S.fwd, S.up, S.row_order, S.row_order_n);
     }
-    vxrt::ViewArgs* slot = c->d_views + (size_t)(c->view_seq++ % kViewSlots) * vxrt::kMaxViews;
+    const unsigned vslot = c->view_seq.fetch_add(1u) % kViewSlots, cslot = c->launch_seq.fetch_add(1u) % kTileCounterRing;
+    bool capturing = false, capturing2 = false;
+    VX_HIP(vxrt::ring_acquire(c->views_busy[vslot], stream, capturing));
+    VX_HIP(vxrt::ring_acquire(c->counter_busy[cslot], stream, capturing2));
+    vxrt::ViewArgs* slot = c->d_views + (size_t)vslot * vxrt::kMaxViews;
     VX_HIP(hipMemcpyAsync(slot, host.data(), sizeof(vxrt::ViewArgs) * n, hipMemcpyHostToDevice, stream));
     A.views = slot;
     A.nviews = n;
-    A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
-    vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream);
+    A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + cslot;
+    VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
     VX_HIP(hipGetLastError());
+    VX_HIP(vxrt::ring_release(c->views_busy[vslot], stream, capturing));
+    VX_HIP(vxrt::ring_release(c->counter_busy[cslot], stream, capturing));
     return VXRT_OK;
 }
 
@@ -585,10 +640,13 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     if (!c || !out)
         return fail(VXRT_ERR_INVALID, "NULL argument");
     VX_HIP(hipSetDevice(c->device));
-    VX_HIP(hipDeviceSynchronize());
-    unsigned long long h[vxrt::kStatCount];
-    VX_HIP(hipMemcpy(h, c->d_stats, sizeof(h), hipMemcpyDeviceToHost));
-    VX_HIP(hipMemset(c->d_stats, 0, sizeof(h)));
+    VX_HIP(hipDeviceSynchronize());  // every stream of the device, non-blocking ones included
+    unsigned long long now[vxrt::kStatCount], h[vxrt::kStatCount];
+    VX_HIP(hipMemcpy(now, c->d_stats, sizeof(now), hipMemcpyDeviceToHost));
+    for (int i = 0; i < vxrt::kStatCount; ++i) {  // what was added since the previous read; the device copy only grows
+        h[i] = now[i] - c->stats_base[i];
+        c->stats_base[i] = now[i];
+    }
     out->primary_rays = h[vxrt::kStatPrimary];
     out->shadow_rays = h[vxrt::kStatShadow];
     out->bounce_rays = h[vxrt::kStatBounce];
@@ -665,7 +723,10 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     B.hit = d_hit;
     B.voxel = (long long*)d_voxel;
     B.stats = c->d_stats;
-    B.ticket = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + (c->launch_seq++ % kTileCounterRing);
+    const unsigned tslot = c->launch_seq.fetch_add(1u) % kTileCounterRing;
+    bool capturing = false;
+    VX_HIP(vxrt::ring_acquire(c->counter_busy[tslot], stream, capturing));
+    B.ticket = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + tslot;
     B.persistent_waves = c->persistent_waves;
     B.max_steps = c->batch_max_steps;
     unsigned int* d_dbg = nullptr;
@@ -674,12 +735,15 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
         VX_HIP(hipMemset(d_dbg, 0xFF, 400 * 12 * 4));
         B.dbg_trace = d_dbg;
     }
-    if (stats) {  // a stats request reports this batch alone
-        VX_HIP(hipDeviceSynchronize());
-        VX_HIP(hipMemset(c->d_stats, 0, vxrt::kStatCount * sizeof(unsigned long long)));
+    if (stats) {  // a stats request reports what ran between two device-wide syncs: this batch alone if nothing else is submitted
+        vxrt_frame_stats drop;
+        int rc = vxrt_frame_stats_get(c, &drop);
+        if (rc)
+            return rc;
     }
-    vxrt::launch_trace_batch(B, stats != nullptr, c->kernel_variant, stream);
+    VX_HIP(vxrt::launch_trace_batch(B, stats != nullptr, c->kernel_variant, stream));
     VX_HIP(hipGetLastError());
+    VX_HIP(vxrt::ring_release(c->counter_busy[tslot], stream, capturing));
     if (stats) {
         VX_HIP(hipStreamSynchronize(stream));
         if (d_dbg) {
@@ -762,28 +826,35 @@ int vxrt_trace_batch_host(vxrt_ctx* c, const float* origins, const float* dirs, 
 namespace {
 
 constexpr char kFileMagic[8] = {'V', 'X', 'B', 'R', 'K', 'M', 'A', 'P'};
-constexpr uint32_t kFileVersion = 1;
+constexpr uint32_t kFileVersion = 2;  // 2: position-sensitive stream checksums (sum + sum of running sums)
 constexpr size_t kFileChunk = 64u << 20;  // staging buffer for the table streams
 
-struct FileHeader {  // 104 bytes, little endian
+struct FileHeader {  // 120 bytes, little endian
     char magic[8];
     uint32_t version, header_bytes;
     int32_t factor, cdims[3];
     uint64_t ncells, nslots;
     uint64_t coarse_bytes, meta_bytes, pool_bytes;  // the three table streams, in this order after the header
-    uint64_t sum[3];                                 // per stream: sum of its 32-bit words, mod 2^64
-    uint64_t reserved;
+    uint64_t sum[3];                                 // per stream: a = sum of its 32-bit words, mod 2^64
+    uint64_t sum2[3];                                // per stream: b = sum of the running values of a (Fletcher style):
+                                                     // unlike a alone, it changes when words are swapped or moved
 };
-static_assert(sizeof(FileHeader) == 104, "file header layout");
+static_assert(sizeof(FileHeader) == 120, "file header layout");
 
-uint64_t word_sum(const void* p, size_t bytes)
-{
-    const uint32_t* w = static_cast<const uint32_t*>(p);
-    uint64_t s = 0;
-    for (size_t i = 0; i < bytes / 4; ++i)
-        s += w[i];
-    return s;
-}
+struct StreamSum {
+    uint64_t a = 0, b = 0;
+    void add(const void* p, size_t bytes)
+    {
+        const uint32_t* w = static_cast<const uint32_t*>(p);
+        uint64_t a_ = a, b_ = b;
+        for (size_t i = 0; i < bytes / 4; ++i) {
+            a_ += w[i];
+            b_ += a_;
+        }
+        a = a_;
+        b = b_;
+    }
+};
 
 struct FileCloser {
     FILE* f;
@@ -859,14 +930,18 @@ int vxrt_save_world(vxrt_ctx* c, const char* path)
     std::vector<unsigned char> stage(kFileChunk);
     const void* src[3] = {c->d_coarse, c->d_meta, c->d_pool};
     const uint64_t bytes[3] = {h.coarse_bytes, h.meta_bytes, h.pool_bytes};
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 3; ++t) {
+        StreamSum cs;
         for (uint64_t off = 0; off < bytes[t]; off += kFileChunk) {
             const size_t n = (size_t)std::min<uint64_t>(kFileChunk, bytes[t] - off);
             VX_HIP(hipMemcpy(stage.data(), static_cast<const unsigned char*>(src[t]) + off, n, hipMemcpyDeviceToHost));
-            h.sum[t] += word_sum(stage.data(), n);
+            cs.add(stage.data(), n);
             if (fwrite(stage.data(), 1, n, fc.f) != n)
                 return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed (disk full?)");
         }
+        h.sum[t] = cs.a;
+        h.sum2[t] = cs.b;
+    }
     if (fseek(fc.f, 0, SEEK_SET) != 0 || fwrite(&h, sizeof(h), 1, fc.f) != 1 || fflush(fc.f) != 0)
         return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed");
     return VXRT_OK;
@@ -899,12 +974,12 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
         return fail(VXRT_ERR_INVALID, std::string(path) + ": " + why);
     };
     for (int t = 0; t < 3; ++t) {
-        uint64_t sum = 0;
+        StreamSum cs;
         for (uint64_t off = 0; off < bytes[t]; off += kFileChunk) {
             const size_t n = (size_t)std::min<uint64_t>(kFileChunk, bytes[t] - off);
             if (fread(stage.data(), 1, n, fc.f) != n)
                 return bad("file is truncated");
-            sum += word_sum(stage.data(), n);
+            cs.add(stage.data(), n);
             if (t == 0)
                 memcpy(reinterpret_cast<unsigned char*>(coarse.data()) + off, stage.data(), n);
             if (t == 1) {
@@ -915,6 +990,12 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
                     const bool bit = (coarse[cell >> 5] >> (cell & 31)) & 1u;
                     if (bit ? m[i].x >= h.nslots : m[i].x != VXRT_EMPTY_SLOT)
                         return bad("cell table does not match the coarse bits / pool size");
+                    if (bit)  // tight extents: six 5-bit fields {min x,y,z, max x,y,z}, each inside the brick, min <= max
+                        for (int a = 0; a < 3; ++a) {
+                            const uint32_t lo = (m[i].y >> (5 * a)) & 31u, hi = (m[i].y >> (5 * (a + 3))) & 31u;
+                            if (hi >= (uint32_t)h.factor || lo > hi || (m[i].y >> 30) != 0u)
+                                return bad("brick extents outside the brick");
+                        }
                 }
             }
             hipError_t e = hipMemcpy(static_cast<unsigned char*>(dst[t]) + off, stage.data(), n, hipMemcpyHostToDevice);
@@ -923,7 +1004,7 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
                 return fail(VXRT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
             }
         }
-        if (sum != h.sum[t])
+        if (cs.a != h.sum[t] || cs.b != h.sum2[t])
             return bad("checksum mismatch (corrupt file)");
     }
     c->nslots = h.nslots;

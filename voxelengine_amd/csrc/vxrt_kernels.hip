@@ -545,7 +545,7 @@ namespace vxrt {
 
 // variant 0 = wave state machine, one lane per pixel; 1 = straightforward per-lane loops (A/B and cross-check);
 // 2 = persistent waves pulling pixels from a tile queue
-void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
+hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
 {
     // one wave per workgroup: no wave waits for a slower sibling before its slot is reused (+5 % measured)
     static const int threads = getenv("VXRT_BLOCK") ? atoi(getenv("VXRT_BLOCK")) : 64;
@@ -553,13 +553,15 @@ void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t str
     dim3 block(threads == 64 ? 64 : 256, 1, 1);
     dim3 grid((A.width + tile - 1) / tile, (A.launch_rows + tile - 1) / tile, 1);
     if (grid.x == 0 || grid.y == 0)
-        return;
+        return hipSuccess;
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
     if (variant == 2) {
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
         const unsigned waves = ntiles < A.persistent_waves ? (unsigned)ntiles : A.persistent_waves;
-        (void)hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
+        const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
+        if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
+            return e;
         const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
         const dim3 g(waves), b(64);
 #define VXRT_LAUNCH_PERSIST(S, B2, M) hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A)
@@ -575,7 +577,7 @@ void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t str
             else VXRT_LAUNCH_PERSIST(false, false, false);
         }
 #undef VXRT_LAUNCH_PERSIST
-        return;
+        return hipSuccess;
     }
     if (variant == 1) {
         if (stats)
@@ -588,25 +590,28 @@ void launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t str
         else
             hipLaunchKernelGGL(k_render_wave<false>, grid, block, lds, stream, A);
     }
+    return hipSuccess;
 }
 
-void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream)
+hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream)
 {
     if (B.n == 0)
-        return;
+        return hipSuccess;
     dim3 block(256, 1, 1);
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
     // default: persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the
     // persistent grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
     if (variant == 2 && B.ticket && !B.dbg_trace && B.persistent_waves && B.n >= 8ull * 64ull * B.persistent_waves) {
-        (void)hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
+        const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
+        if (e != hipSuccess)
+            return e;
         const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
         const dim3 g((unsigned)(tickets < B.persistent_waves ? tickets : B.persistent_waves)), b(64);
         if (stats)
             hipLaunchKernelGGL(k_trace_batch_persist<true>, g, b, 0, stream, B);
         else
             hipLaunchKernelGGL(k_trace_batch_persist<false>, g, b, 0, stream, B);
-        return;
+        return hipSuccess;
     }
     if (variant == 1) {
         if (stats)
@@ -619,6 +624,7 @@ void launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t
         else
             hipLaunchKernelGGL(k_trace_batch_wave<false>, grid, block, 0, stream, B);
     }
+    return hipSuccess;
 }
 
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,

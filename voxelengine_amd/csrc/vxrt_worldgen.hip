@@ -258,6 +258,7 @@ namespace vxrt {
 int adopt_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t nslots, uint32_t** d_coarse, uint2** d_meta,
                 uint32_t** d_pool);
 int set_error(int code, const char* msg);
+void abandon_world(vxrt_ctx* c);  // frees the tables of a world whose build failed half way
 
 #define WG_HIP(call)                                                                               \
     do {                                                                                           \
@@ -282,8 +283,11 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
     const uint64_t bw = (uint64_t)factor * factor * factor / 32;
     uint32_t *d_scratch = nullptr, *d_ext = nullptr, *d_slot = nullptr;
     uint8_t* d_any = nullptr;
+    bool adopted = false, done = false;
     auto cleanup = [&]() {
         (void)hipFree(d_scratch); (void)hipFree(d_ext); (void)hipFree(d_slot); (void)hipFree(d_any);
+        if (adopted && !done)
+            abandon_world(c);  // a failed pack / coarse-bit pass must not leave a half-built world flagged resident
     };
     WG_HIP(hipMalloc((void**)&d_scratch, ncells * bw * sizeof(uint32_t)));
     WG_HIP(hipMalloc((void**)&d_ext, ncells * sizeof(uint32_t)));
@@ -320,6 +324,7 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
         cleanup();
         return rc;
     }
+    adopted = true;
     hipLaunchKernelGGL(k_pack_bricks, grid, block, 0, 0, (const uint4*)d_scratch, d_slot, d_ext, (uint4*)d_pool, d_meta,
                        (uint32_t)(bw / 4), (uint32_t)ncells);
     WG_HIP(hipGetLastError());
@@ -327,6 +332,7 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
     hipLaunchKernelGGL(k_coarse_bits, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, 0, d_any, d_coarse, ncells);
     WG_HIP(hipGetLastError());
     WG_HIP(hipDeviceSynchronize());
+    done = true;
     cleanup();
     return VXRT_OK;
 }
