@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <string>
@@ -144,6 +145,21 @@ int main(int argc, char** argv)
 
     double avgFrameTime = 0.0;
     const int nframes = path.empty() ? frames : (int)path.size();
+    // buffers of the two-frames-in-flight mode (allocated before the timed frame loop, like d_pixels)
+    void* d_ring[3] = {d_pixels, nullptr, nullptr};
+    BGRA8888* h_ring[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t rendered[3], copied[3];
+    hipStream_t copy_stream;
+    const size_t bytes = (size_t)width * height * sizeof(BGRA8888);
+    if (hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking) != hipSuccess)
+        return 1;
+    for (int k = 0; k < 3 && in_flight >= 2 && batch <= 1; ++k) {
+        if ((k > 0 && hipMalloc(&d_ring[k], bytes) != hipSuccess) || hipHostMalloc((void**)&h_ring[k], bytes) != hipSuccess ||
+            hipEventCreateWithFlags(&rendered[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&copied[k], hipEventDisableTiming) != hipSuccess)
+            return 1;
+        (void)hipMemset(d_ring[k], 255, bytes);
+    }
     vxrt_frame_stats rays_before{};
     (void)vxrt_frame_stats_get(raytracer->Context(), &rays_before);  // start the ray counters of the frame loop from zero
     const auto loop0 = std::chrono::high_resolution_clock::now();
@@ -158,15 +174,11 @@ int main(int argc, char** argv)
         dump_ms += std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::high_resolution_clock::now() - d0).count() / 1000.0;
     };
     if (batch <= 1 && in_flight >= 2) {
-        // Two frames in flight (Graphics::RenderScreenAsync): launch frame i, THEN wait for frame i-1 and copy it to the host
-        // -- the per-frame sequence of VoxelApp/main.cu:165-167 shifted by one frame.  The camera of frame i may depend on
-        // anything the host knows when it launches it (input, frame i-2's pixels); nothing is batched ahead.
-        void* d_ring[2] = {d_pixels, nullptr};
-        if (hipMalloc(&d_ring[1], (size_t)width * height * sizeof(BGRA8888)) != hipSuccess)
-            return 1;
-        (void)hipMemset(d_ring[1], 255, (size_t)width * height * sizeof(BGRA8888));
-        FrameTicket tickets[2] = {0, 0};
-        for (int i = 0; i <= nframes; ++i) {
+        // Two frames in flight (Graphics::RenderScreenAsync): launch frame i, queue its device->host copy behind it on the
+        // frame's stream, THEN take delivery of frame i-2 -- the per-frame sequence of VoxelApp/main.cu:165-167 with the
+        // host two frames ahead of the pixels.  The camera of frame i may depend on anything the host knows when it launches
+        // it; nothing is batched ahead.  Three device buffers and three pinned host buffers rotate.
+        for (int i = 0; i < nframes + 2; ++i) {
             auto f0 = std::chrono::high_resolution_clock::now();
             if (i < nframes) {
                 if (!path.empty()) {
@@ -174,18 +186,23 @@ int main(int argc, char** argv)
                     cam_eular = path[(size_t)i].euler;
                 }
                 GetDirections(cam_eular, &cam_forward, &cam_up, &cam_right);
-                tickets[i % 2] = RenderScreenAsync(raytracer, width, height, d_ring[i % 2], cam_pos, cam_forward, cam_up, cam_right);
+                const FrameTicket t = RenderScreenAsync(raytracer, width, height, d_ring[i % 3], cam_pos, cam_forward, cam_up, cam_right);
+                // the copy runs on its own stream behind the frame, so the render streams never wait for the copy engine
+                (void)hipEventRecord(rendered[i % 3], (hipStream_t)FrameStream(t));
+                (void)hipStreamWaitEvent(copy_stream, rendered[i % 3], 0);
+                (void)hipMemcpyAsync(h_ring[i % 3], d_ring[i % 3], bytes, hipMemcpyDeviceToHost, copy_stream);
+                (void)hipEventRecord(copied[i % 3], copy_stream);
             }
-            if (i > 0) {
-                WaitFrame(tickets[(i - 1) % 2]);
-                (void)hipMemcpy(pixels.data(), d_ring[(i - 1) % 2], pixels.size() * sizeof(BGRA8888), hipMemcpyDeviceToHost);
-                timed_dump(i - 1);
+            if (i >= 2) {  // frame i-2 is delivered (its device buffer is the one frame i+1 will render into)
+                (void)hipEventSynchronize(copied[(i - 2) % 3]);
+                if (dump_all || i - 2 == nframes - 1)
+                    std::memcpy(pixels.data(), h_ring[(i - 2) % 3], bytes);
+                timed_dump(i - 2);
             }
             auto f1 = std::chrono::high_resolution_clock::now();
             double td = std::chrono::duration_cast<std::chrono::microseconds>(f1 - f0).count() / 1000.0;
             avgFrameTime = i == 0 ? td : avgFrameTime * 0.9 + td * 0.1;
         }
-        (void)hipFree(d_ring[1]);
     }
     if (batch > 1) {
         // several poses per launch (Graphics::RenderScreens): every view has its own framebuffer, so this mode runs
@@ -256,6 +273,14 @@ int main(int argc, char** argv)
     auto res = raytracer->Raytrace(o, d);
     for (int i = 0; i < 4; ++i)
         std::printf("ray %d valid=%d steps=%d voxel=%d\n", i, (int)res.valid[i], res.steps[i], res.voxelIndex[i]);
+    for (int k = 0; k < 3 && in_flight >= 2 && batch <= 1; ++k) {
+        if (k > 0)
+            (void)hipFree(d_ring[k]);
+        (void)hipHostFree(h_ring[k]);
+        (void)hipEventDestroy(rendered[k]);
+        (void)hipEventDestroy(copied[k]);
+    }
+    (void)hipStreamDestroy(copy_stream);
     (void)hipFree(d_pixels);
     delete raytracer;
     return 0;

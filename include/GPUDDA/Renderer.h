@@ -55,8 +55,10 @@ void RenderScreens(VoxelRaytracer3D* rt, uint32_t screen_width, uint32_t screen_
 // frames are in flight and the wavefronts of frame k+1 fill the SIMD slots that the last, longest rays of frame k leave
 // (a single 1080p frame keeps the GPU full for only ~70 % of its launch; measured 3.3 -> 4.6 Grays/s).  The frame is exactly
 // the frame RenderScreen produces.  Give consecutive frames different device buffers; WaitFrame(ticket) returns once that
-// frame is complete (then the device->host copy of VoxelApp/main.cu:167 may read it).  A third unfinished frame makes
-// RenderScreenAsync wait for the oldest one first.
+// frame is complete (then the device->host copy of VoxelApp/main.cu:167 may read it).  The call never blocks: frame t queues
+// behind frame t-2 on their common stream, so at most two frames execute at once however far ahead the caller runs; a caller
+// paces itself with WaitFrame (which waits for the newest frame launched on the ticket's stream, a later one of the same
+// parity included).
 typedef uint64_t FrameTicket;
 FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t screen_width, uint32_t screen_height, void* d_screen_texture,
                               float3 origin, float3 camera_fwd, float3 camera_up, float3 camera_right);

@@ -124,7 +124,7 @@ def test_damaged_files_are_rejected_and_leave_no_world(eng, vxo, tmp_path):
         off = meta_off + occupied * 8 + 4
         bad[off:off + 4] = struct.pack("<I", ext)
         meta = np.frombuffer(bytes(bad[meta_off:pool_off]), np.uint32).astype(np.uint64)
-        a = int(meta.sum() % (1 << 64))
+        a = int(meta.sum(dtype=np.uint64))   # uint64 arithmetic wraps, as the file's sums do
         run = np.cumsum(meta, dtype=np.uint64)
         b = int(run.sum(dtype=np.uint64))
         hdr = list(struct.unpack(HEADER, bytes(bad[:HEADER_BYTES])))

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/flythrough.sh <out-tag>   (on the GPU box via gpurun)
-# The reference's call pattern at the headline configuration: examples/voxelapp_headless flies 96 poses through the
+# The reference's call pattern at the headline configuration: examples/voxelapp_headless flies 480 poses through the
 # 8192x512x8192 world at 1920x1080 (shaded: primary + shadow + 1 bounce sample, whole frames), one RenderScreen-shaped call
 # per frame with the device->host copy of every frame, first synchronously (Graphics::RenderScreen, as VoxelApp/main.cu
 # does), then with two frames in flight (Graphics::RenderScreenAsync / WaitFrame).  Prints the example's own Mrays/s.
@@ -11,8 +11,8 @@ mkdir -p $OUT
 python3 - > $OUT/path.txt <<'PY'
 import math
 X, Y, Z = 8192, 512, 8192
-for i in range(96):
-    t = i / 95.0
+for i in range(480):
+    t = i / 479.0
     a = 0.7 + 2.4 * t
     x = X * (0.5 + 0.3 * math.cos(6.0 * t)); z = Z * (0.5 + 0.3 * math.sin(6.0 * t))
     y = Y * (0.75 + 0.2 * math.sin(9.0 * t))

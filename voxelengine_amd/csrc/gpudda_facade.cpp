@@ -385,9 +385,9 @@ FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void
         // non-blocking: the two streams overlap each other and do not join the caller's default stream
         hip_ok(hipStreamCreateWithFlags(&g_frames.stream[s], hipStreamNonBlocking), "hipStreamCreateWithFlags");
         hip_ok(hipEventCreateWithFlags(&g_frames.done[s], hipEventDisableTiming), "hipEventCreateWithFlags");
-    } else {
-        hip_ok(hipEventSynchronize(g_frames.done[s]), "hipEventSynchronize");  // frame t-2 used this slot
     }
+    // (no host wait here: frame t queues behind frame t-2 on their common stream, so at most two frames EXECUTE at once
+    // however far ahead the caller runs; callers pace themselves with WaitFrame)
     fl.stream = g_frames.stream[s];
     const float o[3] = {origin.x, origin.y, origin.z}, f[3] = {fwd.x, fwd.y, fwd.z}, u[3] = {up.x, up.y, up.z},
                 r[3] = {right.x, right.y, right.z};
@@ -398,8 +398,10 @@ FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void
 
 void WaitFrame(FrameTicket t)
 {
-    if (t == 0 || t > g_frames.issued || t + 2 <= g_frames.issued)
-        return;  // never issued, or older than the two frames that can be in flight: already complete
+    if (t == 0 || t > g_frames.issued)
+        return;  // never issued
+    // the event of the newest frame on t's stream: frames of one parity complete in order, so this covers frame t (and
+    // waits for a later frame of the same parity if the caller has already launched one)
     hip_ok(hipEventSynchronize(g_frames.done[t % 2]), "hipEventSynchronize");
 }
 
