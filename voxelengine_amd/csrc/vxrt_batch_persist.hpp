@@ -149,8 +149,7 @@ __global__ __launch_bounds__(64, 4) void k_trace_batch_persist(BatchArgs B)
                         T.phase_end(W);
                 }
             }
-            for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
-                T.step(W);
+            T.probe_group(W);
         }
     }
 

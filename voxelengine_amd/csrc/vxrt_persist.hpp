@@ -475,8 +475,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_persist(RenderA
                         dg_park_ticks += wall_clock64();
                 }
             }
-            for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
-                T.step(W);
+            T.probe_group(W);
         }
     }
 

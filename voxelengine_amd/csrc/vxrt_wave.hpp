@@ -377,6 +377,125 @@ struct WaveTracer {
         st = lane_test(park) ? (uint32_t)ST_BOX : (lane_test(ending) ? (uint32_t)ST_END : st);
     }
 
+    // Two probes with both occupancy loads in flight together.  The cell of the second probe is known before the first
+    // word arrives -- a DDA's path does not depend on the voxels, only where it stops does -- so its load is issued ahead of
+    // the first probe's `s_waitcnt` instead of behind it (the straightforward pair exposed the whole latency of the second
+    // load: the compiler had ~8 independent instructions to put between that load and its use).  A lane that does not
+    // advance in the first probe is not walking in the second, so the speculative word is simply unused.  Same results as
+    // step(); step(): 3 more vector instructions per pair (the next cell is computed, then committed by select).
+    __device__ __forceinline__ void step2(const WorldView& W)
+    {
+        // ---- probe 1: address, load
+        const lanemask_t w1 = lane_mask(st == ST_WALK);
+        const lanemask_t in1 = lane_mask((uint32_t)cell_x < (uint32_t)lim_x) & lane_mask((uint32_t)cell_y < (uint32_t)lim_y) &
+                               lane_mask((uint32_t)cell_z < (uint32_t)lim_z);
+        const uint32_t idx1_raw = tiled_index(min(cell_x, dm1_x), min(cell_y, dm1_y), min(cell_z, dm1_z), tw, twh);
+        const uint32_t idx1 = lane_test(in1) ? idx1_raw : 0u;
+        uint32_t word1 = 0u;
+        if (!MASKED_LOAD || st == ST_WALK)
+            word1 = bits[idx1 >> 5];
+        const lanemask_t is_fine = lane_mask(fine != 0u), skipping = lane_mask(skip != 0u);
+        // ---- probe 1: the DDA advance, as far as it does not need the word (:293-322)
+        const lanemask_t lt_xy = lane_mask(tn_x < tn_y), lt_xz = lane_mask(tn_x < tn_z), lt_yz = lane_mask(tn_y < tn_z);
+        const lanemask_t ax0 = lt_xy & lt_xz, ax1 = ~lt_xy & lt_yz, ax2 = ~(ax0 | ax1);
+        const bool on0 = lane_test(ax0), on1 = lane_test(ax1), on2 = lane_test(ax2);
+        const float t = on0 ? tn_x : (on1 ? tn_y : tn_z);
+        const float crx = on0 ? (float)(cell_x + up_x) : ws.x + (t * d.x);
+        const float cry = on1 ? (float)(cell_y + up_y) : ws.y + (t * d.y);
+        const float crz = on2 ? (float)(cell_z + up_z) : ws.z + (t * d.z);
+        const float cmin = fminf(fminf(crx, cry), crz), cmax = fmaxf(fmaxf(crx, cry), crz);
+        const lanemask_t outside1 = (lane_mask(cmin < 0.0f) | lane_mask(cmax > W.ff)) & is_fine;
+        // the cell the lane is in next if it advances, and ITS load
+        const int nx = cell_x + (on0 ? 2 * up_x - 1 : 0), ny = cell_y + (on1 ? 2 * up_y - 1 : 0), nz = cell_z + (on2 ? 2 * up_z - 1 : 0);
+        const lanemask_t in2 = lane_mask((uint32_t)nx < (uint32_t)lim_x) & lane_mask((uint32_t)ny < (uint32_t)lim_y) &
+                               lane_mask((uint32_t)nz < (uint32_t)lim_z);
+        const uint32_t idx2_raw = tiled_index(min(nx, dm1_x), min(ny, dm1_y), min(nz, dm1_z), tw, twh);
+        const uint32_t idx2 = lane_test(in2) ? idx2_raw : 0u;
+        uint32_t word2 = 0u;
+        if (!MASKED_LOAD || st == ST_WALK)
+            word2 = bits[idx2 >> 5];
+        // ---- probe 1: decision and commit
+        {
+            const lanemask_t solid = lane_mask(((word1 >> (idx1 & 31u)) & 1u) != 0u) & ~skipping;
+            if (STATS) {
+                const lanemask_t probed = w1 & in1 & ~skipping;
+                cnt.fine_probes += lane_test(probed & is_fine) ? 1u : 0u;
+                cnt.coarse_probes += lane_test(probed & ~is_fine) ? 1u : 0u;
+            }
+            const lanemask_t leave_oob = w1 & ~in1, leave_hit = w1 & in1 & solid & is_fine, park = w1 & in1 & solid & ~is_fine;
+            const lanemask_t adv = w1 & in1 & ~solid;
+            skip = lane_test(w1) ? 0u : skip;
+            const lanemask_t region_oob = outside1 & adv, ok = adv & ~region_oob;
+            const bool moved = lane_test(adv), counted = lane_test(ok);
+            cell_x = moved ? nx : cell_x;
+            cell_y = moved ? ny : cell_y;
+            cell_z = moved ? nz : cell_z;
+            tn_x = lane_test(adv & ax0) ? tn_x + tdx : tn_x;
+            tn_y = lane_test(adv & ax1) ? tn_y + tdy : tn_y;
+            tn_z = lane_test(adv & ax2) ? tn_z + tdz : tn_z;
+            w_code = counted ? (on0 ? 1u : (on1 ? 2u : 3u)) : w_code;
+            point.x = counted ? crx : point.x;
+            point.y = counted ? cry : point.y;
+            point.z = counted ? crz : point.z;
+            steps += counted ? 1 : 0;
+            const lanemask_t exhausted = ok & lane_mask(steps >= kMaxSteps);
+            wf = lane_test(leave_hit) ? (wf | (uint32_t)WF_HIT) : wf;
+            wf = lane_test(leave_oob | region_oob) ? (wf | (uint32_t)WF_OOB) : wf;
+            const lanemask_t ending = leave_oob | leave_hit | region_oob | exhausted;
+            st = lane_test(park) ? (uint32_t)ST_BOX : (lane_test(ending) ? (uint32_t)ST_END : st);
+        }
+        // ---- probe 2: a lane still walking advanced in probe 1, so (nx,ny,nz) is its cell and word2 its word
+        {
+            const lanemask_t w = lane_mask(st == ST_WALK);
+            const lanemask_t solid = lane_mask(((word2 >> (idx2 & 31u)) & 1u) != 0u);  // (skip is clear for every walking lane)
+            if (STATS) {
+                const lanemask_t probed = w & in2;
+                cnt.fine_probes += lane_test(probed & is_fine) ? 1u : 0u;
+                cnt.coarse_probes += lane_test(probed & ~is_fine) ? 1u : 0u;
+            }
+            const lanemask_t leave_oob = w & ~in2, leave_hit = w & in2 & solid & is_fine, park = w & in2 & solid & ~is_fine;
+            const lanemask_t adv = w & in2 & ~solid;
+            const lanemask_t l_xy = lane_mask(tn_x < tn_y), l_xz = lane_mask(tn_x < tn_z), l_yz = lane_mask(tn_y < tn_z);
+            const lanemask_t b0 = l_xy & l_xz, b1 = ~l_xy & l_yz, b2 = ~(b0 | b1);
+            const bool o0 = lane_test(b0), o1 = lane_test(b1), o2 = lane_test(b2);
+            const float t2 = o0 ? tn_x : (o1 ? tn_y : tn_z);
+            const float c2x = o0 ? (float)(cell_x + up_x) : ws.x + (t2 * d.x);
+            const float c2y = o1 ? (float)(cell_y + up_y) : ws.y + (t2 * d.y);
+            const float c2z = o2 ? (float)(cell_z + up_z) : ws.z + (t2 * d.z);
+            const float mn = fminf(fminf(c2x, c2y), c2z), mx = fmaxf(fmaxf(c2x, c2y), c2z);
+            const lanemask_t region_oob = (lane_mask(mn < 0.0f) | lane_mask(mx > W.ff)) & is_fine & adv;
+            const lanemask_t ok = adv & ~region_oob;
+            const bool c0 = lane_test(adv & b0), c1 = lane_test(adv & b1), c2 = lane_test(adv & b2), counted = lane_test(ok);
+            cell_x += c0 ? 2 * up_x - 1 : 0;
+            cell_y += c1 ? 2 * up_y - 1 : 0;
+            cell_z += c2 ? 2 * up_z - 1 : 0;
+            tn_x = c0 ? tn_x + tdx : tn_x;
+            tn_y = c1 ? tn_y + tdy : tn_y;
+            tn_z = c2 ? tn_z + tdz : tn_z;
+            w_code = counted ? (o0 ? 1u : (o1 ? 2u : 3u)) : w_code;
+            point.x = counted ? c2x : point.x;
+            point.y = counted ? c2y : point.y;
+            point.z = counted ? c2z : point.z;
+            steps += counted ? 1 : 0;
+            const lanemask_t exhausted = ok & lane_mask(steps >= kMaxSteps);
+            wf = lane_test(leave_hit) ? (wf | (uint32_t)WF_HIT) : wf;
+            wf = lane_test(leave_oob | region_oob) ? (wf | (uint32_t)WF_OOB) : wf;
+            const lanemask_t ending = leave_oob | leave_hit | region_oob | exhausted;
+            st = lane_test(park) ? (uint32_t)ST_BOX : (lane_test(ending) ? (uint32_t)ST_END : st);
+        }
+    }
+
+    // one group of VXRT_STEPS_PER_ROUND probes between two votes
+    __device__ __forceinline__ void probe_group(const WorldView& W)
+    {
+#if VXRT_STEPS_PER_ROUND == 2 && !defined(VXRT_NO_STEP2)
+        step2(W);
+#else
+        for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
+            step(W);
+#endif
+    }
+
     // Raytrace's epilogue (:514-523)
     __device__ __forceinline__ void result(const WorldView& W, TraceResult& out) const
     {
@@ -432,8 +551,7 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
             row[5] = __float_as_uint(T.tn_x); row[6] = __float_as_uint(T.tn_y); row[7] = __float_as_uint(T.tn_z);
             row[8] = (unsigned)T.steps; row[9] = (unsigned)T.total; row[10] = __float_as_uint(T.ws.x); row[11] = __float_as_uint(T.ws.y);
         }
-        for (int s = 0; s < VXRT_STEPS_PER_ROUND; ++s)
-            T.step(W);
+        T.probe_group(W);
     }
     T.result(W, out);
     if (STATS) {
