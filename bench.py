@@ -234,6 +234,15 @@ def run(args):
         ctx.RenderViews(W, H, views_of(args.warmup + k, frames if not sharded else local), opts(stats=True))  # `local`: scratch
     sp = ctx.frame_stats()
     assert sp.total_rays() == rays_local, "ray counts differ between the timed and the counting pass"
+    if os.environ.get("BENCH_DIAG") and rank == 0:  # wave-loop diagnostics of the counting launches (development)
+        g = [int(v) for v in sp.dbg]
+        it = max(g[0], 1)
+        print("diag: iterations/launch/wave %.0f  walking lanes/iteration %.1f  probes/iteration %.1f | per 100 iterations "
+              "(lanes per run): next/pass %.1f (%.1f)  end %.1f (%.1f)  box %.1f (%.1f) | time share next/pass+retire %.1f%%  "
+              "box+end (first vote of a round) %.1f%%" % (
+                  g[0] / args.steps / 4096.0, g[1] / it, (sp.coarse_probes + sp.fine_probes) / it, 100.0 * g[4] / it, g[7] / max(g[4], 1),
+                  100.0 * g[2] / it, g[5] / max(g[2], 1), 100.0 * g[3] / it, g[6] / max(g[3], 1), 100.0 * g[10] / max(g[8], 1),
+                  100.0 * g[11] / max(g[8], 1)), file=sys.stderr, flush=True)
     bytes_local = sp.algorithmic_bytes()
 
     tot = torch.tensor([float(rays_local), float(bytes_local), float(sum(kernel_ms))], dtype=torch.float64, device=red_dev)
@@ -339,8 +348,9 @@ def run(args):
                 if world > 1 else "none", "rays_per_step": round(rays_total / args.steps, 1),
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
             },
-            "roofline": {"bound": "hbm", "kernel": "k_render_persist<false,%s,%s>" % ("true" if args.bounce_depth == 2 else "false",
-                                                                                    "true" if V > 1 else "false"),
+            "roofline": {"bound": "hbm", "kernel": "%s<false,%s,%s>" % (
+                             "k_render_pool" if (V > 1 and ctx.kernel_variant in (3, 4)) else "k_render_persist",
+                             "true" if args.bounce_depth == 2 else "false", "true" if V > 1 else "false"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(bytes_total / n_launch, 1),

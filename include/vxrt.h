@@ -45,10 +45,11 @@ int vxrt_destroy(vxrt_ctx *ctx);
 /* message of the last failing call on this thread (never NULL) */
 const char *vxrt_last_error(void);
 int vxrt_synchronize(vxrt_ctx *ctx);
-/* kernel implementation used by vxrt_render / vxrt_trace_batch: 2 = persistent waves pulling pixels from a tile
- * queue (default; the batch trace uses the wave-level state machine), 0 = wave-level state machine with one lane
- * per pixel, 1 = straightforward per-lane loops.  All give identical results; 0 and 1 exist for A/B timing and
- * as on-device cross-checks. */
+/* kernel implementation used by vxrt_render / vxrt_render_views (and vxrt_trace_batch): 4 (default) = persistent waves,
+ * with the pixel-per-lane kernel (2) for single-view launches and the LDS pixel-pool kernel (3) for multi-view launches;
+ * 2 / 3 = that kernel for every launch; 0 = wave-level state machine with one lane per pixel; 1 = straightforward
+ * per-lane loops.  All give identical results; the non-default ones exist for A/B timing and as on-device cross-checks.
+ * (Batch traces: 1 = straightforward, anything else = the wave-level tracer / its persistent ray queue.) */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 
 /* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,

@@ -96,7 +96,7 @@ def test_hip_million_ray_batch(vxo, case):
             ctx.set_kernel_variant(variant)
             _check_against_fixture(ctx.Raytrace(o, d), g, "hitPoint")
         # the same world built on the device
-        ctx.set_kernel_variant(2)
+        ctx.set_kernel_variant(4)
         c = G.CONFIG0
         ctx.build_world(c["gen"], c["dims"][0], c["dims"][1], c["dims"][2], c["factor"])
         _check_against_fixture(ctx.Raytrace(o, d), g, "hitPoint")

@@ -73,7 +73,7 @@ def test_hip_reproduces_golden_traces(eng, vxo, name):
         assert np.array_equal(r["voxel"], g["voxel"])
         assert np.array_equal(r["hitPoint"].view(np.uint32), g["pos_bits"])
         assert np.array_equal(r["normal"].astype(np.int8), g["normal"])
-    ctx.set_kernel_variant(2)
+    ctx.set_kernel_variant(4)
 
 
 @pytest.mark.gpu
@@ -98,7 +98,7 @@ def test_hip_reproduces_golden_frames(eng, vxo, name):
         st = ctx.frame_stats()
         assert np.array_equal(fb.cpu().numpy(), g["fb"]) and np.array_equal(hit.cpu().numpy(), g["hit"])
         assert [st.primary_rays, st.shadow_rays, st.bounce_rays, st.primary_hits] == g["rays"].tolist()
-    ctx.set_kernel_variant(2)
+    ctx.set_kernel_variant(4)
 
 
 @pytest.mark.gpu

@@ -95,7 +95,7 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
     """Variants: 0 wave state machine (one lane per pixel), 1 straightforward per-lane loops, 2 persistent waves
     with a pixel queue.  All give the oracle's bits, in every render mode."""
@@ -151,7 +151,7 @@ def test_quirk_cases_on_gpu(eng, vxo):
             _upload(ctx, w)
             e = case["expect"]
             ctx.set_batch_max_steps(case["max_steps"])
-            for variant in (2, 0, 1):
+            for variant in (2, 0, 1, 3):
                 ctx.set_kernel_variant(variant)
                 r = ctx.Raytrace([o], [d], want_stats=True)
                 assert bool(r["hit"][0]) == e["hit"] and int(r["steps"][0]) == e["steps"], (name, variant)
@@ -423,7 +423,7 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("variant", [2, 0])
+@pytest.mark.parametrize("variant", [2, 3, 4, 0])
 def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
     """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).
     Every view must be byte for byte the frame RenderScreen produces for it -- frame, hit-index AOV and colour AOV --

@@ -55,7 +55,8 @@ struct vxrt_ctx {
     float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
     float ortho[2] = {10.0f, 10.0f};
     uint32_t frame_counter = 0;
-    int kernel_variant = 2;          // render: 2 = persistent waves (default), 0 = wave state machine, 1 = straightforward
+    int kernel_variant = 4;          // render: 4 = persistent waves, pool kernel for multi-view launches (default); 2 / 3 = one of
+                                     // the two persistent kernels everywhere; 0 = wave state machine, 1 = straightforward
     unsigned persistent_waves = 4096;
     unsigned long long* d_stats = nullptr;
     // Counters only ever grow on the device (atomics from any stream); "read and clear" is a host-side snapshot that the
@@ -253,6 +254,9 @@ int vxrt_create(int device, vxrt_ctx** out)
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
         c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
+        if (const char* v = getenv("VXRT_VARIANT"))                       // A/B of the render kernels (tools/)
+            if (atoi(v) >= 0 && atoi(v) <= 4)
+                c->kernel_variant = atoi(v);
         if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments only
             if (atoi(e) > 0 && atoi(e) <= 32)
                 c->persistent_waves = (unsigned)prop.multiProcessorCount * (unsigned)atoi(e);
@@ -284,8 +288,8 @@ int vxrt_destroy(vxrt_ctx* c)
 
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant > 2)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct) or 2 (persistent)");
+    if (!c || variant < 0 || variant > 4)
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS) or 4 (default: 3 for multi-view launches, else 2)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }
@@ -537,7 +541,8 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
         A.launch_rows = height;
     A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
     A.persistent_waves = c->persistent_waves;
-    const bool schedule = fl->tile_schedule && c->kernel_variant == 2;
+    const bool persistent = c->kernel_variant >= 2;
+    const bool schedule = fl->tile_schedule && persistent;
 
     auto frame_number_of = [&](const vxrt_view& v) -> uint32_t {
         if (v.frame_number >= 0)
@@ -546,7 +551,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     };
     auto f3_of = [](const float* p) { return vxrt::f3{p[0], p[1], p[2]}; };
 
-    if (nviews == 0 || c->kernel_variant != 2) {  // single-view kernel arguments; variants 0/1 take the views one by one
+    if (nviews == 0 || !persistent) {  // single-view kernel arguments; variants 0/1 take the views one by one
         for (unsigned v = 0; v < n; ++v) {
             A.frame_number = frame_number_of(views[v]);
             A.origin = f3_of(views[v].origin);
@@ -556,6 +561,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
             A.fb = (uint8_t*)views[v].d_fb;
             A.color_aov = views[v].d_color_aov;
             A.hit_aov = (long long*)views[v].d_hit_aov;
+            A.want_hit_aov = A.hit_aov != nullptr;
             A.tile_order = nviews == 0 ? fl->d_tile_order : nullptr;
             A.row_order_n = 0;
             if (schedule && !A.tile_order)
@@ -586,6 +592,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
         S.fb = (uint8_t*)views[v].d_fb;
         S.color_aov = views[v].d_color_aov;
         S.hit_aov = (long long*)views[v].d_hit_aov;
+        A.want_hit_aov |= S.hit_aov != nullptr;
         if (schedule)
             vxrt::schedule_tile_rows(A, S.fwd, S.up, S.row_order, S.row_order_n);
     }

@@ -539,6 +539,7 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 }  // namespace vxrt
 
 #include "vxrt_persist.hpp"
+#include "vxrt_pool.hpp"
 #include "vxrt_batch_persist.hpp"
 
 namespace vxrt {
@@ -555,7 +556,14 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
     if (grid.x == 0 || grid.y == 0)
         return hipSuccess;
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
-    if (variant == 2) {
+    // 4 = the default: the pool kernel for launches over several views (a wave then works through thousands of pixels and
+    // its pool runs in steady state: +2.8 % over the pixel-per-lane kernel), the pixel-per-lane kernel for one view (a
+    // wave's share of one 1080p frame is ~500 pixels, little more than the pool's fill and drain: -5 %)
+    if (variant == 4)
+        variant = A.nviews >= 2 ? 3 : 2;
+    if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))
+        variant = 2;  // the pool kernel packs the sample counter and the launch column into its slot words
+    if (variant == 2 || variant == 3) {
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
         const unsigned waves = ntiles < A.persistent_waves ? (unsigned)ntiles : A.persistent_waves;
@@ -564,7 +572,13 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             return e;
         const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
         const dim3 g(waves), b(64);
-#define VXRT_LAUNCH_PERSIST(S, B2, M) hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A)
+#define VXRT_LAUNCH_PERSIST(S, B2, M)                                                        \
+    do {                                                                                     \
+        if (variant == 3)                                                                    \
+            hipLaunchKernelGGL((k_render_pool<S, B2, M>), g, b, 0, stream, A);               \
+        else                                                                                 \
+            hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A);          \
+    } while (0)
         if (A.nviews) {
             if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, true);
             else if (stats) VXRT_LAUNCH_PERSIST(true, false, true);

@@ -61,6 +61,7 @@ struct RenderArgs {
     // (device memory); the tile queue runs through view 0's tiles, then view 1's, ...
     const struct ViewArgs* views;
     unsigned int nviews;
+    int want_hit_aov;  // some view of the launch has a hit-index AOV (the pool kernel keeps the voxel in the pixel's slot then)
 };
 
 // the per-view part of RenderArgs for a launch that renders several views of the same world

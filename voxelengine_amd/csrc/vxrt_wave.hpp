@@ -68,8 +68,7 @@ template <bool STATS, bool MASKED_LOAD = false>
 struct WaveTracer {
     // per-ray constants
     f3 d;                 // normalised direction
-    float ivx, ivy, ivz;  // 1/(d or eps), slab test
-    float tdx, tdy, tdz;  // |1/d| or inf, DDA
+    float ivx, ivy, ivz;  // 1/(d or eps): the slab test's reciprocal (:127-129), and |iv| is the DDA's tDelta (:199-201)
     int max_steps;
     // Raytrace level
     f3 start;
@@ -87,7 +86,7 @@ struct WaveTracer {
     int steps;  // stepsTaken; also the reference's loop index: an iteration continues exactly when a step is counted
     // coarse results kept across the brick walk
     int chx, chy, chz, nc_axis;
-    uint32_t c_code, slot;
+    uint32_t c_code, slot, c_ci;  // c_ci: tiled index of the coarse HitCell (previous_cell compares it, :402-407)
     const uint32_t* bits;
     RayCounters cnt;
 
@@ -97,7 +96,6 @@ struct WaveTracer {
         fine = wf = w_code = skip = 0u;
         d = mk3(1.0f, 0.0f, 0.0f);
         ivx = ivy = ivz = 1.0f;
-        tdx = tdy = tdz = 1.0f;
         max_steps = 0;
         start = ws = point = hit_pos = mk3(0, 0, 0);
         entry_code = out_code = 0u;
@@ -114,7 +112,7 @@ struct WaveTracer {
         tn_x = tn_y = tn_z = 0.0f;
         steps = 0;
         chx = chy = chz = nc_axis = 0;
-        c_code = slot = 0u;
+        c_code = slot = c_ci = 0u;
         bits = W.coarse_bits;
         cnt = RayCounters{0, 0, 0};
     }
@@ -174,9 +172,9 @@ struct WaveTracer {
         ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // :127-129
         ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
         ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
-        tdx = d.x != 0 ? fabsf(ivx) : kInf;        // :199-201 (same quotient as ivx when d != 0)
-        tdy = d.y != 0 ? fabsf(ivy) : kInf;
-        tdz = d.z != 0 ? fabsf(ivz) : kInf;
+        // tDelta = |1/d|, or inf for d == 0 (:199-201), is not kept: where d != 0 it is |iv| (the same quotient), and an
+        // axis with d == 0 has tMax = inf, is never the smallest, and inf + anything stays inf -- so `tn + |iv|` is
+        // the reference's `tMax + tDelta` in every case
         max_steps = max_steps_;
         up_x = d.x > 0 ? 1 : 0;
         up_y = d.y > 0 ? 1 : 0;
@@ -218,7 +216,7 @@ struct WaveTracer {
         hit_pos.x = is_fine ? point.x + ox : point.x * W.ff;
         hit_pos.y = is_fine ? point.y + oy : point.y * W.ff;
         hit_pos.z = is_fine ? point.z + oz : point.z * W.ff;
-        const uint32_t ci = tiled_index(chx, chy, chz, W.ctw, W.ctwh);
+        const uint32_t ci = c_ci;  // (computed by the tight-box phase that produced this coarse hit)
         // coarse walk ended on an occupied cell that is not the previous_cell (:399-407): enter its brick
         const bool enter = !is_fine && wf == WF_HIT && ci != last_ci;
         const bool fine_hit = is_fine && (wf & WF_HIT) != 0u;  // :493-506
@@ -302,6 +300,7 @@ struct WaveTracer {
         chz = box_hit ? qz : chz;
         c_code = box_hit ? bc : c_code;
         slot = box_hit ? meta.x : slot;
+        c_ci = box_hit ? idx : c_ci;
         // the exit iteration's extra advance (:290-322) only matters through NextCell: keep its axis (bits 0-1)
         // and, per axis, whether the unclamped cell sits one past the clamped HitCell (bits 2-4; edge rule only)
         const int axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
@@ -362,9 +361,9 @@ struct WaveTracer {
         cell_x += c0 ? 2 * up_x - 1 : 0;
         cell_y += c1 ? 2 * up_y - 1 : 0;
         cell_z += c2 ? 2 * up_z - 1 : 0;
-        tn_x = c0 ? tn_x + tdx : tn_x;
-        tn_y = c1 ? tn_y + tdy : tn_y;
-        tn_z = c2 ? tn_z + tdz : tn_z;
+        tn_x = c0 ? tn_x + fabsf(ivx) : tn_x;
+        tn_y = c1 ? tn_y + fabsf(ivy) : tn_y;
+        tn_z = c2 ? tn_z + fabsf(ivz) : tn_z;
         w_code = counted ? (on0 ? 1u : (on1 ? 2u : 3u)) : w_code;  // the axis; its sign is applied at the end of the walk
         point.x = counted ? crx : point.x;
         point.y = counted ? cry : point.y;
@@ -430,9 +429,9 @@ struct WaveTracer {
             cell_x = moved ? nx : cell_x;
             cell_y = moved ? ny : cell_y;
             cell_z = moved ? nz : cell_z;
-            tn_x = lane_test(adv & ax0) ? tn_x + tdx : tn_x;
-            tn_y = lane_test(adv & ax1) ? tn_y + tdy : tn_y;
-            tn_z = lane_test(adv & ax2) ? tn_z + tdz : tn_z;
+            tn_x = lane_test(adv & ax0) ? tn_x + fabsf(ivx) : tn_x;
+            tn_y = lane_test(adv & ax1) ? tn_y + fabsf(ivy) : tn_y;
+            tn_z = lane_test(adv & ax2) ? tn_z + fabsf(ivz) : tn_z;
             w_code = counted ? (on0 ? 1u : (on1 ? 2u : 3u)) : w_code;
             point.x = counted ? crx : point.x;
             point.y = counted ? cry : point.y;
@@ -469,9 +468,9 @@ struct WaveTracer {
             cell_x += c0 ? 2 * up_x - 1 : 0;
             cell_y += c1 ? 2 * up_y - 1 : 0;
             cell_z += c2 ? 2 * up_z - 1 : 0;
-            tn_x = c0 ? tn_x + tdx : tn_x;
-            tn_y = c1 ? tn_y + tdy : tn_y;
-            tn_z = c2 ? tn_z + tdz : tn_z;
+            tn_x = c0 ? tn_x + fabsf(ivx) : tn_x;
+            tn_y = c1 ? tn_y + fabsf(ivy) : tn_y;
+            tn_z = c2 ? tn_z + fabsf(ivz) : tn_z;
             w_code = counted ? (o0 ? 1u : (o1 ? 2u : 3u)) : w_code;
             point.x = counted ? c2x : point.x;
             point.y = counted ? c2y : point.y;

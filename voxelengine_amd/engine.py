@@ -90,7 +90,7 @@ class Context:
         N.check(self._L.vxrt_create(device, C.byref(h)))
         self._h = h
         self.device = device
-        self.kernel_variant = 2  # the library's default (persistent waves)
+        self.kernel_variant = 4  # the library's default (persistent waves; pool kernel for multi-view launches)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -259,7 +259,8 @@ class Context:
 
     def set_kernel_variant(self, variant: int) -> None:
         """0 = wave-level state machine, 1 = straightforward per-lane loops (A/B, cross-check), 2 = persistent
-        waves with a pixel queue."""
+        waves with a pixel queue, 3 = persistent waves with the pixel chains pooled in LDS, 4 = default (3 for
+        multi-view launches, 2 for single-view ones)."""
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
         self.kernel_variant = int(variant)
 
