@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VXRT_ABI_VERSION 1
+#define VXRT_ABI_VERSION 2
 #define VXRT_EMPTY_SLOT 0xFFFFFFFFu
 #define VXRT_MAX_STEPS 2048 /* MAX_STEPS, VoxelRT/VolumeRaytracer.cuh:235 */
 
@@ -165,6 +165,17 @@ typedef struct vxrt_render_flags {
     const uint32_t *d_tile_order; /* optional caller-made hand-out order, overrides tile_schedule: a permutation of
                                 0 .. ceil(W/8)*ceil(rows/8)-1 (tile = tx + ty*ceil(W/8), rows = the launch grid's), or NULL */
     void *stream;
+    /* Temporal accumulation of the stochastic occlusion term -- an EXTENSION: the reference lists "denoise, temporal
+     * accumulation" as to do (README.md:19).  d_accum: W*H*4 floats per pixel {sum r, g, b of the pre-tonemap colour, frames
+     * in the history} (compact shards: their own rows), or NULL = off.  For every shaded hit pixel the colour of
+     * calculateColor (Renderer.cu:90-168) is added to the history and the MEAN is tonemapped and stored; the first frame of
+     * a history (accum_reset != 0, or frames == 0) stores the colour itself.  Miss pixels, the debug view and the overlays
+     * are written as without it.  With a static camera and one frame number per call the bounce noise averages out as 1/n;
+     * the caller resets the history when the camera moves.  vxrt_render only (a multi-view launch has no per-view
+     * history). */
+    float *d_accum;
+    int32_t accum_reset;
+    int32_t reserved_;
 } vxrt_render_flags;
 
 void vxrt_render_flags_default(vxrt_render_flags *flags);

@@ -180,6 +180,10 @@ void vxo_get_directions(const float euler[3], float fwd[3], float up[3], float r
  * hit_aov (optional, width*height int64) receives the primary hit voxel index or -1. */
 void vxo_render(const vxo_world *w, const vxo_render_params *p, uint8_t *fb, float *color_aov,
                 int64_t *hit_aov, vxo_frame_stats *stats, int nthreads);
+/* the same with temporal accumulation (include/vxrt.h, vxrt_render_flags.d_accum): `accum` = W*H*4 floats {sum of the
+ * pre-tonemap colour, frames in the history}; shaded hit pixels only */
+void vxo_render_accum(const vxo_world *w, const vxo_render_params *p, uint8_t *fb, float *color_aov,
+                      int64_t *hit_aov, float *accum, int accum_reset, vxo_frame_stats *stats, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -131,6 +131,8 @@ def lib() -> C.CDLL:
         L.vxo_get_directions.argtypes = [f32p] * 4
         L.vxo_render.argtypes = [C.POINTER(_World), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.POINTER(FrameStats), C.c_int]
+        L.vxo_render_accum.argtypes = [C.POINTER(_World), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.POINTER(FrameStats), C.c_int]
         L.free = C.CDLL(None).free
         L.free.argtypes = [C.c_void_p]
         _LIB = L
@@ -257,7 +259,7 @@ class World:
         return dict(pos=pos, normal=nrm, steps=steps, hit=hit, voxel=vox, stats=st)
 
     def render(self, params: RenderParams, fb: np.ndarray | None = None, want_color=False, want_hit=False,
-               nthreads: int = 8):
+               nthreads: int = 8, accum: np.ndarray | None = None, accum_reset: bool = False):
         W, H = params.width, params.height
         if params.row_end == 0:
             params.row_end = H
@@ -266,8 +268,11 @@ class World:
         col = np.zeros((H, W, 3), np.float32) if want_color else None
         hit = np.full((H, W), -1, np.int64) if want_hit else None
         st = FrameStats()
-        lib().vxo_render(self._p, C.byref(params), fb.ctypes.data, col.ctypes.data if want_color else None,
-                         hit.ctypes.data if want_hit else None, C.byref(st), nthreads)
+        if accum is not None:
+            assert accum.dtype == np.float32 and accum.shape == (H, W, 4) and accum.flags.c_contiguous
+        lib().vxo_render_accum(self._p, C.byref(params), fb.ctypes.data, col.ctypes.data if want_color else None,
+                               hit.ctypes.data if want_hit else None, accum.ctypes.data if accum is not None else None,
+                               int(bool(accum_reset)), C.byref(st), nthreads)
         return dict(fb=fb, color=col, hit=hit, stats=st)
 
 

@@ -64,6 +64,8 @@ typedef struct frame_ctx {
     uint8_t *fb;
     float *color_aov;
     int64_t *hit_aov;
+    float *accum;       /* temporal accumulation (this build's extension): W*H*4 floats {sum r,g,b, frames}, or NULL */
+    int accum_reset;
     uint32_t first_chunk, chunk_stride, rows; /* launch-grid rows for this worker, in chunks of ROW_CHUNK */
     uint32_t grid_w;
     vxo_frame_stats stats;
@@ -187,6 +189,21 @@ static v3 tonemap(v3 c)
     return mk(lo(hi(t.x, 0), 1), lo(hi(t.y, 0), 1), lo(hi(t.z, 0), 1));
 }
 
+/* Temporal accumulation of the stochastic occlusion term (the reference's README lists "denoise, temporal accumulation"
+ * as to do, README.md:19; defined by this build, include/vxrt.h): the pre-tonemap colour of a shaded hit pixel is added
+ * to the pixel's history and the MEAN is what gets tonemapped.  First frame of a history (reset, or no frames yet): the
+ * colour itself. */
+static v3 accumulate(frame_ctx *c, int x, int y, v3 col)
+{
+    float *h = c->accum + ((size_t)y * c->p->width + (size_t)x) * 4;
+    if (c->accum_reset || h[3] == 0.0f) {
+        h[0] = col.x; h[1] = col.y; h[2] = col.z; h[3] = 1.0f;
+        return col;
+    }
+    h[0] = h[0] + col.x; h[1] = h[1] + col.y; h[2] = h[2] + col.z; h[3] = h[3] + 1.0f;
+    return mk(h[0] / h[3], h[1] / h[3], h[2] / h[3]);
+}
+
 /* one launch thread of screenDispatch (Renderer.cu:179-276) */
 static void pixel_thread(frame_ctx *c, uint32_t tx, uint32_t ty)
 {
@@ -248,8 +265,10 @@ static void pixel_thread(frame_ctx *c, uint32_t tx, uint32_t ty)
             } else
                 put_pixel(c, x, y, mk(dist * 0.01f, 0, 0));
         } else {                                 /* :245-251 */
-            v3 col = tonemap(shade(c, tx, ty, origin, normal, pos));
-            put_pixel(c, x, y, col);
+            v3 col = shade(c, tx, ty, origin, normal, pos);
+            if (c->accum)
+                col = accumulate(c, x, y, col);
+            put_pixel(c, x, y, tonemap(col));
         }
     } else {
         put_pixel(c, x, y, ray);                 /* :254-258 */
@@ -293,6 +312,12 @@ static void stats_add(vxo_frame_stats *a, const vxo_frame_stats *b)
 void vxo_render(const vxo_world *w, const vxo_render_params *p, uint8_t *fb, float *color_aov,
                 int64_t *hit_aov, vxo_frame_stats *stats, int nthreads)
 {
+    vxo_render_accum(w, p, fb, color_aov, hit_aov, NULL, 0, stats, nthreads);
+}
+
+void vxo_render_accum(const vxo_world *w, const vxo_render_params *p, uint8_t *fb, float *color_aov,
+                      int64_t *hit_aov, float *accum, int accum_reset, vxo_frame_stats *stats, int nthreads)
+{
     uint32_t rows = p->checkerboard ? (p->height >> 1) : p->height;
     uint32_t grid_w = ((p->width + 31u) / 32u) * 32u;
     if (nthreads < 1)
@@ -310,6 +335,8 @@ void vxo_render(const vxo_world *w, const vxo_render_params *p, uint8_t *fb, flo
         c->fb = fb;
         c->color_aov = color_aov;
         c->hit_aov = hit_aov;
+        c->accum = accum;
+        c->accum_reset = accum_reset;
         c->grid_w = grid_w;
         c->rows = rows;
         c->first_chunk = (uint32_t)i;

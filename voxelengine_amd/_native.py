@@ -61,6 +61,7 @@ class RenderFlags(C.Structure):
         ("strip_rows", C.c_int32), ("strip_count", C.c_int32), ("strip_index", C.c_int32), ("compact", C.c_int32),
         ("collect_stats", C.c_int32), ("tile_schedule", C.c_int32),
         ("d_color_aov", C.c_void_p), ("d_hit_aov", C.c_void_p), ("d_tile_order", C.c_void_p), ("stream", C.c_void_p),
+        ("d_accum", C.c_void_p), ("accum_reset", C.c_int32), ("reserved_", C.c_int32),
     ]
 
 

@@ -496,6 +496,10 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     for (unsigned v = 0; v < n; ++v)
         if (!views[v].d_fb)
             return fail(VXRT_ERR_INVALID, "a view has no framebuffer");
+    if (fl->d_accum && nviews != 0)
+        return fail(VXRT_ERR_INVALID, "temporal accumulation (d_accum) is per view: use vxrt_render");
+    if (fl->d_accum && (reinterpret_cast<uintptr_t>(fl->d_accum) & 15u))
+        return fail(VXRT_ERR_INVALID, "d_accum must be 16-byte aligned");
     VX_HIP(hipSetDevice(c->device));
     hipStream_t stream = (hipStream_t)fl->stream;
 
@@ -527,6 +531,8 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     A.strip_count = fl->strip_count > 1 ? fl->strip_count : 1;
     A.strip_index = fl->strip_index;
     A.compact = fl->compact ? 1 : 0;
+    A.accum = reinterpret_cast<float4*>(fl->d_accum);
+    A.accum_reset = fl->accum_reset ? 1 : 0;
     A.strip_shift = -1;
     for (int b = 0; b < 31; ++b)
         if (A.strip_rows == (1 << b))

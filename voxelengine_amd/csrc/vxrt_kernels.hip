@@ -64,6 +64,21 @@ struct PixelSink {
     }
 };
 
+// Temporal accumulation (include/vxrt.h, vxrt_render_flags.d_accum): add the pre-tonemap colour of a shaded hit pixel to its
+// history and return the mean; the first frame of a history returns the colour itself.  One float4 load + store per pixel.
+__device__ __forceinline__ f3 accumulate_color(const RenderArgs& A, int out_row, int x, f3 c)
+{
+    float4* h = A.accum + ((size_t)out_row * A.width + (size_t)x);
+    float4 v = *h;
+    if (A.accum_reset || v.w == 0.0f) {
+        *h = make_float4(c.x, c.y, c.z, 1.0f);
+        return c;
+    }
+    v = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, v.w + 1.0f);
+    *h = v;
+    return mk3(v.x / v.w, v.y / v.w, v.z / v.w);
+}
+
 // calculateColor (Renderer.cu:90-168) with the shadow ray (:102) and the sample count (:123) as run-time flags
 __device__ f3 shade(const RenderArgs& A, uint32_t tx, uint32_t ty, f3 cam, f3 normal, f3 position,
                     RayCounters& cnt, uint32_t& n_shadow, uint32_t& n_bounce)
@@ -209,6 +224,8 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A)
                     sink.put(x, y, mk3(dist * 0.01f, 0, 0));
             } else {  // Renderer.cu:245-251
                 f3 c = shade(A, tx, ty, origin, normal, pr.pos, cnt, n_shadow, n_bounce);
+                if (A.accum)
+                    c = accumulate_color(A, out_row, x, c);
                 c = mk3(c.x / (c.x + 1.0f), c.y / (c.y + 1.0f), c.z / (c.z + 1.0f));  // Tonemap, :170-177
                 c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
                 sink.put(x, y, c);
@@ -459,6 +476,8 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
                 } else
                     sink.put(x, y, mk3(dist * 0.01f, 0, 0));
             } else {
+                if (A.accum)
+                    color = accumulate_color(A, out_row, x, color);
                 f3 c = mk3(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));  // Tonemap
                 c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
                 sink.put(x, y, c);

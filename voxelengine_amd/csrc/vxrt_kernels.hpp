@@ -61,6 +61,8 @@ struct RenderArgs {
     // (device memory); the tile queue runs through view 0's tiles, then view 1's, ...
     const struct ViewArgs* views;
     unsigned int nviews;
+    float4* accum;       // temporal accumulation history (vxrt_render_flags.d_accum), single-view launches only, or NULL
+    int accum_reset;
     int want_hit_aov;  // some view of the launch has a hit-index AOV (the pool kernel keeps the voxel in the pixel's slot then)
 };
 

@@ -106,6 +106,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
                 } else
                     sink.put(pc.x, pc.y, mk3(dist * 0.01f, 0, 0));
             } else {
+                if (!MULTI && A.accum)  // temporal accumulation (extension, include/vxrt.h): the mean of the history is tonemapped
+                    shaded = accumulate_color(A, pc.out_row, pc.x, shaded);
                 f3 c = mk3(shaded.x / (shaded.x + 1.0f), shaded.y / (shaded.y + 1.0f), shaded.z / (shaded.z + 1.0f));  // Tonemap
                 c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
                 sink.put(pc.x, pc.y, c);

@@ -164,13 +164,16 @@ class Context:
 
     # ---- per frame -------------------------------------------------------------------------------
     def RenderScreen(self, width: int, height: int, d_fb, origin, fwd, up, right, opts: RenderOptions | None = None,
-                     color_aov=None, hit_aov=None, stream: int | None = None, tile_order=None) -> None:
+                     color_aov=None, hit_aov=None, stream: int | None = None, tile_order=None, accum=None,
+                     accum_reset: bool = False) -> None:
         """Graphics::RenderScreen (VoxelRT/Renderer.cu:305-328).  ``d_fb``/AOVs: torch CUDA tensors or raw
         device addresses.  Asynchronous on ``stream`` (default: torch's current stream)."""
         fl = self._flags(opts, stream)
         fl.d_color_aov = _ptr(color_aov)
         fl.d_hit_aov = _ptr(hit_aov)
         fl.d_tile_order = _ptr(tile_order)
+        fl.d_accum = _ptr(accum)  # temporal accumulation history, (H, W, 4) float32 (extension, include/vxrt.h)
+        fl.accum_reset = int(bool(accum_reset))
         N.check(self._L.vxrt_render(self._h, width, height, _ptr(d_fb), _f3(origin), _f3(fwd), _f3(up), _f3(right),
                                     C.byref(fl)))
 
@@ -195,6 +198,8 @@ class Context:
         right`` and optionally ``frame_number`` (default: ``opts.frame_number``, or the context counter), ``color_aov``,
         ``hit_aov``.  Every view equals what :meth:`RenderScreen` produces for it."""
         fl = self._flags(opts, stream)
+        if opts is not None and opts.extra.get("accum") is not None:
+            fl.d_accum = _ptr(opts.extra["accum"])  # rejected by the library: a multi-view launch has no per-view history
         arr = (N.View * len(views))()
         for dst, v in zip(arr, views):
             dst.d_fb = _ptr(v["fb"])
