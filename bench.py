@@ -320,6 +320,7 @@ def run(args):
         avg_kernel_s = kernel_ms_total / 1e3 / n_launch
         achieved = (bytes_total / n_launch) / avg_kernel_s / 1e9
         traffic = None
+        issue = None
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj):
             try:
@@ -328,6 +329,7 @@ def run(args):
                 ent = tab.get(args.workload + "_single_view_launch", {}) if V == 1 else tab.get(args.workload, {})
                 if world == 1 and ent.get("views_per_launch", 1 if V == 1 else None) == V:
                     traffic = ent.get("hbm_bytes_per_launch")
+                    issue = ent.get("issue_utilisation")
             except Exception:
                 traffic = None
         result = {
@@ -355,7 +357,17 @@ def run(args):
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(bytes_total / n_launch, 1),
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
-                         "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1)},
+                         "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1),
+                         # what the fraction above is and is not: the contract's yardstick is ALGORITHMIC bytes on the
+                         # reference's data layout; the bytes that really cross the HBM interface (PMC, profiles/) are a
+                         # fraction of them, and the kernel's physical limiter is instruction issue per wavefront
+                         "convention": "achieved = algorithmic bytes (SURVEY.md 8d: 28 B per coarse probe, 24 B per brick entry, "
+                                       "4 B per brick probe, 4 B per pixel) / launch time; not measured HBM traffic",
+                         "traffic_frac": None if traffic is None else round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
+                         "physical_bound": "instruction issue per wavefront at 4 waves/SIMD (divergent traversal); "
+                                           "issue_utilisation = instructions issued per SIMD cycle against the rate the same "
+                                           "instruction mix reaches in profiles/r02_issue_rate_ubench.txt",
+                         "issue_utilisation": issue},
         }
         if rehearse or args.force_gather:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
             full = torch.zeros_like(frames)

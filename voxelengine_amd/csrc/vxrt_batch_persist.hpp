@@ -31,8 +31,11 @@ namespace vxrt {
 #endif
 constexpr uint32_t kBatchTicket = 64u;  // rays per queue ticket (256 or 1024: 7 % slower on incoherent rays, no faster on short ones)
 
+#ifndef VXRT_BATCH_OCC
+#define VXRT_BATCH_OCC 4
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(64, 4) void k_trace_batch_persist(BatchArgs B)
+__global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(BatchArgs B)
 {
     const WorldView& W = B.W;
     const int lane = threadIdx.x & 63;
