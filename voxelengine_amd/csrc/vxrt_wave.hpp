@@ -384,6 +384,13 @@ struct WaveTracer {
     // step(); step(): 3 more vector instructions per pair (the next cell is computed, then committed by select).
     __device__ __forceinline__ void step2(const WorldView& W)
     {
+#if !defined(VXRT_HOST_CHECK) && !defined(VXRT_NO_ENTRY_WAIT)
+        // Start from a KNOWN memory scoreboard.  The pair is entered from every phase's exit, some with stores or loads still
+        // outstanding; at such a join the compiler's wait insertion no longer knows how many, and the first use of word1
+        // got `s_waitcnt vmcnt(0)` -- waiting for word2 as well, the very latency the pair is built to hide.  With
+        // everything older drained here (it would be waited for a few instructions later anyway), word1 waits with vmcnt(1).
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0) only
+#endif
         // ---- probe 1: address, load
         const lanemask_t w1 = lane_mask(st == ST_WALK);
         const lanemask_t in1 = lane_mask((uint32_t)cell_x < (uint32_t)lim_x) & lane_mask((uint32_t)cell_y < (uint32_t)lim_y) &
