@@ -104,7 +104,7 @@ int vxrt_download_world(vxrt_ctx *ctx, uint32_t *coarse_bits, uint32_t *brick_sl
  * CreateVoxels + GenerateLowresVoxelBuffer, minutes at 8k scale on its host threads); a built brickmap can be
  * kept instead.  Layout (little endian): 104-byte header {"VXBRKMAP", u32 version = 1, u32 header bytes,
  * i32 factor, i32 cdims[3], u64 ncells, u64 nslots, u64 bytes of the three streams, u64 word sums of the three
- * streams, u64 reserved}, then the streams as they lie in HBM: coarse_bits (as in vxrt_world_desc), one 8-byte
+ * streams, u64 sums of the running word sums of the three streams (position-sensitive)}, then the streams as they lie in HBM: coarse_bits (as in vxrt_world_desc), one 8-byte
  * record per cell {u32 pool slot or VXRT_EMPTY_SLOT, u32 extents: min x,y,z then max x,y,z, 5 bits each from bit 0}
  * in the order of coarse_bits, and the pool.  Loading validates sizes, sums and the cell table against the coarse
  * bits, and streams through a 64 MiB staging buffer. */
@@ -112,6 +112,30 @@ int vxrt_save_world(vxrt_ctx *ctx, const char *path);
 int vxrt_load_world(vxrt_ctx *ctx, const char *path);
 /* header of a brickmap file (no GPU needed); hbm_bytes = bytes the three streams will occupy */
 int vxrt_world_file_info(const char *path, vxrt_world_info *out);
+
+/* ---- chunk streaming -- an EXTENSION: the reference lists "Chunking" and "Chunk data streaming" as to do
+ * (README.md:15,20).  A world whose bricks need not all be resident: the coarse tables of the whole world stay in HBM
+ * (128 KiB + 8 MiB for 8192x512x8192), the brick pool is a cache of `pool_capacity_bricks` bricks, and brick data is
+ * read from a brickmap file (vxrt_save_world) for the CHUNKS near a focus point only.  A chunk is one 8x8x8 tile of
+ * coarse cells -- 512 consecutive records of the tiled-linear tables and one contiguous run of bricks in the file, so a
+ * chunk arrives with one read and three copies.  A chunk that is not resident reads as EMPTY space: the kernels do not
+ * change, and every frame equals the frame of the world with exactly the resident chunks' bricks (tests hold the HIP
+ * frames equal to the oracle on that truncated world).
+ *   vxrt_stream_open: replaces the context's world by the (so far empty) streamed world of `path`.
+ *   vxrt_stream_focus: makes every chunk whose box lies within `radius` voxels of `focus` resident, nearest first;
+ *     when the pool is full, resident chunks OUTSIDE the radius are evicted, farthest first; chunks inside the radius
+ *     that still do not fit stay absent (stats.chunks_missing).  Synchronises the device before it touches the tables.
+ *   vxrt_stream_resident: one byte per chunk (chunk = tile index of the coarse grid), 1 = resident. */
+typedef struct vxrt_stream_stats {
+    uint64_t chunks_total, chunks_occupied;   /* tiles of the coarse grid; those holding at least one brick */
+    uint64_t chunks_resident, bricks_resident;
+    uint64_t chunks_loaded, chunks_evicted, chunks_missing;  /* by this call */
+    uint64_t bytes_read;                                      /* from the file, by this call */
+} vxrt_stream_stats;
+int vxrt_stream_open(vxrt_ctx *ctx, const char *path, uint64_t pool_capacity_bricks);
+int vxrt_stream_focus(vxrt_ctx *ctx, const float focus[3], float radius, vxrt_stream_stats *stats_or_null);
+int vxrt_stream_resident(vxrt_ctx *ctx, uint8_t *flags, uint64_t n_chunks);
+int vxrt_stream_close(vxrt_ctx *ctx);
 
 /* ---- camera / lighting state.  Replaces Graphics::SetEnvironment, ::SetFOV,
  * ::SetOrthoWindowSize, ::GetDirections (VoxelRT/Renderer.cu:27-42,278-303). */

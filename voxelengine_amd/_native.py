@@ -20,7 +20,7 @@ EXPORTS = [
     "vxrt_set_environment", "vxrt_set_fov", "vxrt_set_ortho_window_size", "vxrt_get_directions",
     "vxrt_render_flags_default", "vxrt_render", "vxrt_render_views", "vxrt_compact_rows", "vxrt_frame_stats_get",
     "vxrt_deinterleave_strips", "vxrt_deinterleave_views", "vxrt_trace_batch", "vxrt_trace_batch_host",
-    "vxrt_set_batch_max_steps",
+    "vxrt_set_batch_max_steps", "vxrt_stream_open", "vxrt_stream_focus", "vxrt_stream_resident", "vxrt_stream_close",
 ]
 
 
@@ -51,6 +51,12 @@ class FrameStats(C.Structure):
         per_primary = 52 if batch else 4
         return int(self.coarse_probes * 28 + self.brick_entries * 24 + self.fine_probes * 4
                    + self.primary_rays * per_primary)
+
+
+class StreamStats(C.Structure):
+    _fields_ = [("chunks_total", C.c_uint64), ("chunks_occupied", C.c_uint64), ("chunks_resident", C.c_uint64),
+                ("bricks_resident", C.c_uint64), ("chunks_loaded", C.c_uint64), ("chunks_evicted", C.c_uint64),
+                ("chunks_missing", C.c_uint64), ("bytes_read", C.c_uint64)]
 
 
 class RenderFlags(C.Structure):
@@ -131,6 +137,10 @@ def load() -> C.CDLL:
     L.vxrt_trace_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.POINTER(FrameStats), C.c_void_p]
     L.vxrt_set_batch_max_steps.argtypes = [C.c_void_p, C.c_int32]
+    L.vxrt_stream_open.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64]
+    L.vxrt_stream_focus.argtypes = [C.c_void_p, f3, C.c_float, C.POINTER(StreamStats)]
+    L.vxrt_stream_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.vxrt_stream_close.argtypes = [C.c_void_p]
     L.vxrt_trace_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]
     for name in EXPORTS:

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <utility>
@@ -71,6 +72,7 @@ struct vxrt_ctx {
     std::atomic<unsigned> view_seq{0};
     hipEvent_t views_busy[16] = {};
     int batch_max_steps = vxrt::kMaxSteps;  // Raytrace's maxSteps for the batch API (vxrt_set_batch_max_steps)
+    struct StreamState* stream = nullptr;   // chunk streaming (vxrt_stream_*), or NULL
 };
 constexpr unsigned kViewSlots = 16;  // multi-view launches that may be in flight at once on one context
 constexpr unsigned kTileCounterRing = 64;  // render launches that may be in flight at once on one context
@@ -79,8 +81,11 @@ static_assert(kViewSlots == sizeof(vxrt_ctx::views_busy) / sizeof(hipEvent_t), "
 
 namespace vxrt {
 
+void stream_drop(vxrt_ctx* c);  // defined with the chunk streaming code below
+
 static void free_world(vxrt_ctx* c)
 {
+    stream_drop(c);
     if (c->d_coarse) (void)hipFree(c->d_coarse);
     if (c->d_meta) (void)hipFree(c->d_meta);
     if (c->d_pool) (void)hipFree(c->d_pool);
@@ -1023,6 +1028,290 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
     c->nslots = h.nslots;
     vxrt::fill_view(c, h.factor, cd);
     c->has_world = true;
+    return VXRT_OK;
+}
+
+}  // extern "C"
+
+// ---- chunk streaming (include/vxrt.h): coarse tables of the whole world resident, brick data only near the focus --------
+struct StreamState {
+    FILE* f = nullptr;
+    FileHeader h{};
+    uint64_t pool_off = 0, brick_bytes = 0, nchunks = 0;
+    std::vector<uint32_t> coarse;   // the whole world's coarse bits
+    std::vector<uint2> meta;        // ... and cell records, with the FILE's slot numbers
+    struct Chunk {
+        uint32_t first_slot = 0, nbricks = 0;   // its run of bricks in the file
+        int64_t base = -1;                      // first brick of its range in the device pool, or -1 = not resident
+        float lo[3], hi[3];                     // its box in voxels
+    };
+    std::vector<Chunk> chunks;
+    std::map<uint64_t, uint64_t> free_ranges;   // device pool: start -> length, in bricks
+    uint64_t capacity = 0, bricks_resident = 0, chunks_resident = 0, chunks_occupied = 0;
+
+    bool alloc(uint64_t n, uint64_t& start)
+    {
+        for (auto it = free_ranges.begin(); it != free_ranges.end(); ++it)
+            if (it->second >= n) {  // first fit
+                start = it->first;
+                const uint64_t rest = it->second - n, at = it->first + n;
+                free_ranges.erase(it);
+                if (rest)
+                    free_ranges[at] = rest;
+                return true;
+            }
+        return false;
+    }
+    void release(uint64_t start, uint64_t n)
+    {
+        auto next = free_ranges.lower_bound(start);
+        if (next != free_ranges.begin()) {  // merge with the range that ends where this one starts
+            auto prev = std::prev(next);
+            if (prev->first + prev->second == start) {
+                start = prev->first;
+                n += prev->second;
+                free_ranges.erase(prev);
+            }
+        }
+        if (next != free_ranges.end() && start + n == next->first) {
+            n += next->second;
+            free_ranges.erase(next);
+        }
+        free_ranges[start] = n;
+    }
+};
+
+namespace vxrt {
+void stream_drop(vxrt_ctx* c)
+{
+    if (!c->stream)
+        return;
+    if (c->stream->f)
+        fclose(c->stream->f);
+    delete c->stream;
+    c->stream = nullptr;
+}
+}  // namespace vxrt
+
+extern "C" {
+
+int vxrt_stream_open(vxrt_ctx* c, const char* path, uint64_t pool_capacity_bricks)
+{
+    if (!c || !path || pool_capacity_bricks == 0)
+        return fail(VXRT_ERR_INVALID, "NULL argument or empty pool");
+    FILE* f = fopen(path, "rb");
+    if (!f)
+        return fail(VXRT_ERR_INVALID, std::string(path) + ": cannot open");
+    StreamState* S = new (std::nothrow) StreamState();
+    if (!S) {
+        fclose(f);
+        return fail(VXRT_ERR_NOMEM, "out of host memory");
+    }
+    S->f = f;
+    auto bad = [&](int code, const std::string& why) {
+        fclose(S->f);
+        delete S;
+        return fail(code, why);
+    };
+    int rc = read_header(f, path, S->h);
+    if (rc) {
+        fclose(S->f);
+        delete S;
+        return rc;
+    }
+    const FileHeader& h = S->h;
+    S->coarse.resize(h.coarse_bytes / 4);
+    S->meta.resize(h.ncells);
+    if (fread(S->coarse.data(), 1, h.coarse_bytes, f) != h.coarse_bytes || fread(S->meta.data(), 1, h.meta_bytes, f) != h.meta_bytes)
+        return bad(VXRT_ERR_INVALID, std::string(path) + ": file is truncated");
+    {   // the two table streams are checked like vxrt_load_world checks them (the pool is read chunk by chunk later)
+        StreamSum a, b;
+        a.add(S->coarse.data(), h.coarse_bytes);
+        b.add(S->meta.data(), h.meta_bytes);
+        if (a.a != h.sum[0] || a.b != h.sum2[0] || b.a != h.sum[1] || b.b != h.sum2[1])
+            return bad(VXRT_ERR_INVALID, std::string(path) + ": checksum mismatch (corrupt file)");
+    }
+    S->pool_off = sizeof(FileHeader) + h.coarse_bytes + h.meta_bytes;
+    S->brick_bytes = (uint64_t)h.factor * h.factor * h.factor / 8;
+    S->nchunks = h.ncells / 512;
+    S->chunks.resize(S->nchunks);
+    const int tw = h.cdims[0] / 8, th = h.cdims[1] / 8;
+    uint32_t next_slot = 0;
+    for (uint64_t ch = 0; ch < S->nchunks; ++ch) {
+        StreamState::Chunk& C = S->chunks[ch];
+        C.first_slot = next_slot;
+        for (uint64_t i = ch * 512; i < ch * 512 + 512; ++i) {
+            const bool bit = (S->coarse[i >> 5] >> (i & 31)) & 1u;
+            // slots run through the file in cell order (vxrt_save_world writes what the builders produce): a chunk's
+            // bricks are ONE contiguous run
+            if (bit ? S->meta[i].x != next_slot : S->meta[i].x != VXRT_EMPTY_SLOT)
+                return bad(VXRT_ERR_INVALID, std::string(path) + ": brick slots are not in cell order");
+            if (bit) {
+                ++next_slot;
+                ++C.nbricks;
+            }
+        }
+        const int tx = (int)(ch % tw), ty = (int)((ch / tw) % th), tz = (int)(ch / ((uint64_t)tw * th));
+        const float e = 8.0f * (float)h.factor;
+        C.lo[0] = tx * e; C.lo[1] = ty * e; C.lo[2] = tz * e;
+        C.hi[0] = C.lo[0] + e; C.hi[1] = C.lo[1] + e; C.hi[2] = C.lo[2] + e;
+        if (C.nbricks)
+            S->chunks_occupied += 1;
+    }
+    if (next_slot != h.nslots)
+        return bad(VXRT_ERR_INVALID, std::string(path) + ": brick count does not match the coarse bits");
+    // device: the whole world's tables (all empty for now) + a pool of the requested capacity
+    int cd[3] = {h.cdims[0], h.cdims[1], h.cdims[2]};
+    if (hipSetDevice(c->device) != hipSuccess)
+        return bad(VXRT_ERR_HIP, "hipSetDevice");
+    (void)hipDeviceSynchronize();
+    rc = vxrt::alloc_world(c, h.factor, cd, pool_capacity_bricks);  // (frees a previous world, streamed or not)
+    if (rc) {
+        fclose(S->f);
+        delete S;
+        return rc;
+    }
+    std::vector<uint2> empty(h.ncells, make_uint2(VXRT_EMPTY_SLOT, 0u));
+    hipError_t e = hipMemset(c->d_coarse, 0, h.coarse_bytes);
+    if (e == hipSuccess)
+        e = hipMemcpy(c->d_meta, empty.data(), h.meta_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        vxrt::free_world(c);
+        return bad(VXRT_ERR_HIP, std::string("stream tables: ") + hipGetErrorString(e));
+    }
+    S->capacity = pool_capacity_bricks;
+    S->free_ranges[0] = pool_capacity_bricks;
+    c->nslots = pool_capacity_bricks;
+    vxrt::fill_view(c, h.factor, cd);
+    c->has_world = true;
+    c->stream = S;
+    return VXRT_OK;
+}
+
+int vxrt_stream_focus(vxrt_ctx* c, const float focus[3], float radius, vxrt_stream_stats* out)
+{
+    if (!c || !focus || !(radius >= 0.0f))
+        return fail(VXRT_ERR_INVALID, "NULL argument or negative radius");
+    StreamState* S = c->stream;
+    if (!S)
+        return fail(VXRT_ERR_NO_WORLD, "no streamed world (vxrt_stream_open)");
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());  // no launch may read the tables while chunks come and go
+    // squared distance of the focus to every occupied chunk's box
+    std::vector<std::pair<float, uint32_t>> order;
+    order.reserve(S->chunks_occupied);
+    for (uint64_t ch = 0; ch < S->nchunks; ++ch) {
+        const StreamState::Chunk& C = S->chunks[ch];
+        if (!C.nbricks)
+            continue;
+        float d2 = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            const float d = focus[a] < C.lo[a] ? C.lo[a] - focus[a] : (focus[a] > C.hi[a] ? focus[a] - C.hi[a] : 0.0f);
+            d2 += d * d;
+        }
+        order.emplace_back(d2, (uint32_t)ch);
+    }
+    std::stable_sort(order.begin(), order.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    const float r2 = radius * radius;
+    uint64_t loaded = 0, evicted = 0, missing = 0, bytes = 0;
+    size_t far = order.size();  // eviction candidates: from the far end of the order, outside the radius only
+    std::vector<unsigned char> stage;
+    std::vector<uint2> meta(512);
+    auto write_tables = [&](uint32_t ch, bool resident) -> hipError_t {
+        const StreamState::Chunk& C = S->chunks[ch];
+        uint32_t k = 0;
+        for (uint64_t i = 0; i < 512; ++i) {
+            const uint2 m = S->meta[(uint64_t)ch * 512 + i];
+            meta[i] = (resident && m.x != VXRT_EMPTY_SLOT) ? make_uint2((uint32_t)(C.base + k++), m.y) : make_uint2(VXRT_EMPTY_SLOT, 0u);
+        }
+        hipError_t e = hipMemcpy(c->d_meta + (uint64_t)ch * 512, meta.data(), 512 * sizeof(uint2), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return e;
+        uint32_t bits[16];  // one 8x8x8 tile of coarse cells = 512 bits = one 64-byte line
+        for (int w = 0; w < 16; ++w)
+            bits[w] = resident ? S->coarse[(uint64_t)ch * 16 + w] : 0u;
+        return hipMemcpy(c->d_coarse + (uint64_t)ch * 16, bits, sizeof(bits), hipMemcpyHostToDevice);
+    };
+    for (size_t k = 0; k < order.size() && order[k].first <= r2; ++k) {
+        const uint32_t ch = order[k].second;
+        StreamState::Chunk& C = S->chunks[ch];
+        if (C.base >= 0)
+            continue;
+        uint64_t start = 0;
+        bool ok = S->alloc(C.nbricks, start);
+        while (!ok && far > 0) {  // make room: the farthest resident chunk outside the radius goes
+            --far;
+            if (order[far].first <= r2)
+                break;
+            StreamState::Chunk& V = S->chunks[order[far].second];
+            if (V.base < 0)
+                continue;
+            VX_HIP(write_tables(order[far].second, false));
+            S->release((uint64_t)V.base, V.nbricks);
+            S->bricks_resident -= V.nbricks;
+            S->chunks_resident -= 1;
+            V.base = -1;
+            evicted += 1;
+            ok = S->alloc(C.nbricks, start);
+        }
+        if (!ok) {
+            missing += 1;
+            continue;
+        }
+        const uint64_t nbytes = (uint64_t)C.nbricks * S->brick_bytes;
+        stage.resize(nbytes);
+        if (fseek(S->f, (long)(S->pool_off + (uint64_t)C.first_slot * S->brick_bytes), SEEK_SET) != 0 ||
+            fread(stage.data(), 1, nbytes, S->f) != nbytes) {
+            S->release(start, C.nbricks);
+            return fail(VXRT_ERR_INVALID, "brickmap file: chunk read failed");
+        }
+        bytes += nbytes;
+        hipError_t e = hipMemcpy(reinterpret_cast<unsigned char*>(c->d_pool) + start * S->brick_bytes, stage.data(), nbytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            S->release(start, C.nbricks);
+            return fail(VXRT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
+        }
+        C.base = (int64_t)start;
+        VX_HIP(write_tables(ch, true));
+        S->bricks_resident += C.nbricks;
+        S->chunks_resident += 1;
+        loaded += 1;
+    }
+    if (out) {
+        out->chunks_total = S->nchunks;
+        out->chunks_occupied = S->chunks_occupied;
+        out->chunks_resident = S->chunks_resident;
+        out->bricks_resident = S->bricks_resident;
+        out->chunks_loaded = loaded;
+        out->chunks_evicted = evicted;
+        out->chunks_missing = missing;
+        out->bytes_read = bytes;
+    }
+    return VXRT_OK;
+}
+
+int vxrt_stream_resident(vxrt_ctx* c, uint8_t* flags, uint64_t n_chunks)
+{
+    if (!c || !flags)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    if (!c->stream)
+        return fail(VXRT_ERR_NO_WORLD, "no streamed world (vxrt_stream_open)");
+    if (n_chunks != c->stream->nchunks)
+        return fail(VXRT_ERR_INVALID, "one flag per 8x8x8 tile of the coarse grid");
+    for (uint64_t ch = 0; ch < n_chunks; ++ch)
+        flags[ch] = c->stream->chunks[ch].base >= 0 ? 1 : 0;
+    return VXRT_OK;
+}
+
+int vxrt_stream_close(vxrt_ctx* c)
+{
+    if (!c)
+        return fail(VXRT_ERR_INVALID, "ctx is NULL");
+    if (!c->stream)
+        return VXRT_OK;
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());
+    vxrt::free_world(c);  // drops the stream state with the tables
     return VXRT_OK;
 }
 

@@ -21,6 +21,14 @@
 
 namespace vxrt {
 
+// branch weight for the voted phases: told that they are the rare path, the register allocator keeps its spills out of
+// the probe code (experiment knob)
+#ifdef VXRT_COLD_PHASES
+#define VXRT_RARE(c) __builtin_expect(!!(c), 0)
+#else
+#define VXRT_RARE(c) (c)
+#endif
+
 #ifndef VXRT_POOL_SLOTS
 #define VXRT_POOL_SLOTS 128
 #endif
@@ -469,7 +477,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             dg_walk += (unsigned long long)c_walk;
         }
         // parked phases as a cascade on fresh votes (see k_render_persist)
-        if (vote_run(c_box, c_walk, VXRT_VOTE_BOX)) {
+        if (VXRT_RARE(vote_run(c_box, c_walk, VXRT_VOTE_BOX))) {
             if (STATS) {
                 dg_runs[2] += 1u;
                 dg_lanes[2] += (unsigned)c_box;
@@ -480,7 +488,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             c_walk = __popcll(__ballot(T.st == ST_WALK));
             c_end = __popcll(__ballot(T.st == ST_END));
         }
-        if (vote_run(c_end, c_walk + c_box, VXRT_VOTE_END)) {
+        if (VXRT_RARE(vote_run(c_end, c_walk + c_box, VXRT_VOTE_END))) {
             if (STATS) {
                 dg_runs[1] += 1u;
                 dg_lanes[1] += (unsigned)c_end;
@@ -496,7 +504,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             const int c_free = __popcll(__ballot(T.st == ST_FREE));
             const int feed = c_done + (c_free < (int)q_count ? c_free : (int)q_count);
             const int busy = c_walk + c_box + c_end;
-            if (vote_run(feed, busy, VXRT_VOTE_RETIRE)) {
+            if (VXRT_RARE(vote_run(feed, busy, VXRT_VOTE_RETIRE))) {
                 if (STATS)
                     dg_park_ticks -= wall_clock64();  // (in this kernel: the time in retire + refill)
                 retire();
@@ -507,8 +515,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             // the pass: when the queue runs low and there is something to continue or to start
             const uint32_t startable = drained ? 0u : nfree;
             const int hungry = __popcll(__ballot(T.st == ST_FREE));
-            if (q_count <= (uint32_t)VXRT_POOL_LOW && (nfin + startable) > 0u &&
-                (nfin + startable >= (uint32_t)VXRT_POOL_MINPASS || hungry >= 8 || __popcll(__ballot(T.st == ST_WALK || T.st == ST_BOX || T.st == ST_END)) == 0)) {
+            if (VXRT_RARE(q_count <= (uint32_t)VXRT_POOL_LOW && (nfin + startable) > 0u &&
+                (nfin + startable >= (uint32_t)VXRT_POOL_MINPASS || hungry >= 8 || __popcll(__ballot(T.st == ST_WALK || T.st == ST_BOX || T.st == ST_END)) == 0))) {
                 if (STATS) {
                     dg_runs[0] += 1u;
                     dg_next_ticks -= wall_clock64();
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             if (g > 0) {
                 int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
                     m_e = __popcll(__ballot(T.st == ST_END));
-                if (vote_run(m_b, m_w, VXRT_VOTE_BOX)) {
+                if (VXRT_RARE(vote_run(m_b, m_w, VXRT_VOTE_BOX))) {
                     if (STATS) {
                         dg_runs[2] += 1u;
                         dg_lanes[2] += (unsigned)m_b;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
                     m_w = __popcll(__ballot(T.st == ST_WALK));
                     m_e = __popcll(__ballot(T.st == ST_END));
                 }
-                if (vote_run(m_e, m_w + m_b, VXRT_VOTE_END)) {
+                if (VXRT_RARE(vote_run(m_e, m_w + m_b, VXRT_VOTE_END))) {
                     if (STATS) {
                         dg_runs[1] += 1u;
                         dg_lanes[1] += (unsigned)m_e;

@@ -139,6 +139,28 @@ class Context:
         N.check(self._L.vxrt_load_world(self._h, os.fsencode(path)))
         return self.world_info()
 
+    # ---- chunk streaming (extension, include/vxrt.h) -------------------------------------------------
+    def stream_open(self, path: str, pool_capacity_bricks: int) -> "N.WorldInfo":
+        """A world whose bricks are read from the brickmap file ``path`` only for the chunks (8x8x8 tiles of coarse
+        cells) near a focus point; the pool is a cache of ``pool_capacity_bricks`` bricks.  Empty until ``stream_focus``."""
+        N.check(self._L.vxrt_stream_open(self._h, os.fsencode(path), int(pool_capacity_bricks)))
+        return self.world_info()
+
+    def stream_focus(self, focus, radius: float) -> "N.StreamStats":
+        st = N.StreamStats()
+        N.check(self._L.vxrt_stream_focus(self._h, _f3(focus), float(radius), C.byref(st)))
+        return st
+
+    def stream_resident(self) -> np.ndarray:
+        """One flag per chunk (tile index of the coarse grid): 1 = its bricks are resident."""
+        info = self.world_info()
+        flags = np.zeros(int(info.ncells) // 512, np.uint8)
+        N.check(self._L.vxrt_stream_resident(self._h, flags.ctypes.data, flags.size))
+        return flags
+
+    def stream_close(self) -> None:
+        N.check(self._L.vxrt_stream_close(self._h))
+
     def download_world(self, with_pool: bool = True):
         info = self.world_info()
         n = int(info.ncells)
