@@ -14,6 +14,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <ostream>
 #include <limits>
 #include <memory>
 #include <tuple>
@@ -84,6 +85,9 @@ public:
     size_t BitSize() const;
     size_t ByteSize() const;
 };
+// prints every bit as 0/1, first bit first (VolumeRaytracer.cu:86-93); host arrays only
+std::ostream& operator<<(std::ostream& os, const BitArray& bits);
+
 
 template <size_t D>
 struct VoxelBuffer {

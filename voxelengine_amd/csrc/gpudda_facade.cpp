@@ -107,6 +107,12 @@ uint32_t* BitArray::Raw() { return data; }
 const uint32_t* BitArray::Raw() const { return data; }
 size_t BitArray::BitSize() const { return size; }
 size_t BitArray::ByteSize() const { return (size + 31) / 32 * sizeof(uint32_t); }
+std::ostream& operator<<(std::ostream& os, const BitArray& bits)
+{
+    for (size_t i = 0; i < bits.BitSize(); ++i)
+        os << bits[i];
+    return os;
+}
 
 // ---- VoxelRaytracer3D ------------------------------------------------------------------------------
 
