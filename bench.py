@@ -298,7 +298,7 @@ def run(args):
             n2 = args.steps * V
             for g in range(n2 + 2):
                 if g < n2:
-                    v = views_of(g // V, frames)[g % V]
+                    v = views_of(args.warmup + g // V, frames)[g % V]  # the timed steps' views, frame numbers included
                     o.frame_number = v["frame_number"]
                     ctx.RenderScreen(W, H, ring[g % 3], v["origin"], v["fwd"], v["up"], v["right"], o, stream=raw[g % 2])
                     done[g % 3].record(ext[g % 2])

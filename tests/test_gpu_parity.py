@@ -198,11 +198,12 @@ def test_batch_max_steps_matches_the_oracle(eng, vxo):
         small.close()
 
 
-def test_eighty_launches_in_flight_over_four_streams(eng, vxo):
+@pytest.mark.parametrize("depth", [1, 2])
+def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth):
     """More launches in flight than the context has queue heads (64 single-view, 16 multi-view): launch 65 waits for launch 1
     instead of sharing its tile counter (vxrt_api.hip ring_acquire).  80 single-view launches and 20 multi-view launches
     over 4 streams, no synchronisation in between; every frame must be the frame a lone launch renders, and the ray
-    counters must add up."""
+    counters must add up.  depth 2 = the second-bounce instantiation of the kernels (the one with the most private state)."""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
@@ -211,7 +212,7 @@ def test_eighty_launches_in_flight_over_four_streams(eng, vxo):
     inv = float(np.float32(1.0) / np.sqrt(np.float32(3.0)))
     ctx.SetEnvironment((inv, inv, inv), (2, 2, 2), (0.5, 0.5, 0.5))
     ctx.SetFOV(90.0)
-    base = dict(shadow=True, bounce_samples=1)
+    base = dict(shadow=True, bounce_samples=1, bounce_depth=depth)
     ref, rays_ref = [], []
     for j, (pos, f, u, r) in enumerate(cams):     # one at a time
         fb = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
