@@ -351,7 +351,7 @@ def run(args):
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
             },
             "roofline": {"bound": "hbm", "kernel": "%s<false,%s,%s>" % (
-                             "k_render_pool" if (V > 1 and ctx.kernel_variant in (3, 4)) else "k_render_persist",
+                             ctx.KERNEL_NAMES[ctx.kernel_for_launch(W, H, opts(), V if V > 1 else 0)],  # the library's choice
                              "true" if args.bounce_depth == 2 else "false", "true" if V > 1 else "false"),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

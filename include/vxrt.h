@@ -45,11 +45,16 @@ int vxrt_destroy(vxrt_ctx *ctx);
 /* message of the last failing call on this thread (never NULL) */
 const char *vxrt_last_error(void);
 int vxrt_synchronize(vxrt_ctx *ctx);
-/* kernel implementation used by vxrt_render / vxrt_render_views (and vxrt_trace_batch): 4 (default) = persistent waves,
- * with the pixel-per-lane kernel (2) for single-view launches and the LDS pixel-pool kernel (3) for multi-view launches;
- * 2 / 3 = that kernel for every launch; 0 = wave-level state machine with one lane per pixel; 1 = straightforward
- * per-lane loops.  All give identical results; the non-default ones exist for A/B timing and as on-device cross-checks.
- * (Batch traces: 1 = straightforward, anything else = the wave-level tracer / its persistent ray queue.) */
+/* kernel implementation used by vxrt_render / vxrt_render_views (and vxrt_trace_batch).  All give identical results.
+ *   4 (default) = persistent waves, the kernel picked per launch from measurements: 5 for a launch over several views
+ *       and for a large single-view launch (at least 4 M rays, counting one shadow and one bounce ray per pixel where
+ *       enabled), 2 for a small one;
+ *   2 = persistent waves, one pixel chain per lane, pixels from a tile queue;
+ *   3 = the same with the pixel chains pooled in LDS;
+ *   5 = 2 with the state only the parked phases touch in LDS: 96 VGPRs, 5 waves per SIMD;
+ *   0 = wave-level state machine with one lane per pixel; 1 = straightforward per-lane loops.
+ * The non-default ones exist for A/B timing and as on-device cross-checks.  (Batch traces: 1 = straightforward,
+ * 0 = the wave-level tracer, anything else = the wave-level tracer behind a persistent ray queue.) */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 
 /* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,
@@ -226,6 +231,9 @@ typedef struct vxrt_view {
 } vxrt_view;
 int vxrt_render_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, uint32_t n_views, const vxrt_view *views,
                       const vxrt_render_flags *flags);
+/* the kernel (0, 1, 2, 3 or 5) a vxrt_render (nviews = 0) or vxrt_render_views launch of this shape would run under the
+ * context's current variant; -1 on bad arguments.  For tools that label measurements by kernel (bench.py). */
+int vxrt_kernel_for_launch(const vxrt_ctx *ctx, uint32_t width, uint32_t height, const vxrt_render_flags *flags, uint32_t nviews);
 /* number of frame rows owned by a shard, = rows of its compact buffer */
 uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_count, int32_t strip_index);
 /* counters accumulated by the launches on this context since the previous read, whatever their streams; synchronises

@@ -49,8 +49,16 @@ int main(int argc, char** argv)
         int h = vxo_raytrace(w, 2048, o, d, &steps, nn, pp, vox, &st);
         TraceResult t; RayCounters c{0, 0, 0};
         trace_wave<true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t, c);
+        // the same tracer with its cold state outside the registers (on the GPU: an LDS column per lane) must agree field by field
+        static uint32_t cold_column[CF_TRACER_FIELDS * 64];
+        TraceResult t2; RayCounters c2{0, 0, 0};
+        trace_wave<true, false, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t2, c2, nullptr, cold_column);
+        bool same2 = t2.hit == t.hit && t2.steps == t.steps && memcmp(&t2.normal, &t.normal, 12) == 0 && c2.coarse_probes == c.coarse_probes &&
+                     c2.brick_entries == c.brick_entries && c2.fine_probes == c.fine_probes;
+        if (t.hit) same2 = same2 && memcmp(&t2.pos, &t.pos, 12) == 0 && t2.vx == t.vx && t2.vy == t.vy && t2.vz == t.vz;
         bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries && c.fine_probes == st.fine_probes;
         if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
+        ok = ok && same2;
         if (!ok && bad++ < 5)
             printf("ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g) cpu hit=%d steps=%d probes=%llu/%llu/%llu | wave hit=%d steps=%d probes=%u/%u/%u\n", i, o[0], o[1], o[2], d[0], d[1], d[2], h, steps,
                    (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries, (unsigned long long)st.fine_probes, t.hit, t.steps, c.coarse_probes, c.brick_entries, c.fine_probes);

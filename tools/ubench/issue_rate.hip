@@ -1,5 +1,5 @@
 // issue_rate.hip -- what one SIMD of gfx950 issues per cycle, measured with pinned instruction streams (inline asm, so the
-// compiler cannot merge, pack or reorder them) at 1, 2, 4 and 8 waves per SIMD.  In-kernel s_memtime stamps give shader
+// compiler cannot merge, pack or reorder them) at 1, 2, 4, 5, 6 and 8 waves per SIMD.  In-kernel s_memtime stamps give shader
 // cycles directly (no assumed clock).  Streams:
 //   valu_indep   8 independent v_fma_f32 chains            -- peak issue rate of plain wave64 VALU
 //   valu_dep     one dependent v_fma_f32 chain              -- dependent-issue latency
@@ -99,7 +99,7 @@ int main()
     printf("# %s, %d CUs; cycles are s_memtime shader cycles inside the kernel, median over workgroups\n", p.name, cus);
     printf("%-13s %10s %26s %26s\n", "stream", "waves/SIMD", "cycles/instr (one wave)", "cycles/instr per SIMD");
     for (int kind = 0; kind < 7; ++kind)
-        for (int wps : {1, 2, 4, 8}) {
+        for (int wps : {1, 2, 4, 5, 6, 8}) {
             const int blocks = cus * 4 * wps;  // 64-thread workgroups: wps waves on every SIMD
             auto launch = [&]() {
                 switch (kind) {

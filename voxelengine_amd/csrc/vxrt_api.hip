@@ -18,6 +18,7 @@
 
 namespace vxrt {
 hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
+int resolve_render_variant(const RenderArgs& A, int variant);
 hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
                          uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream, uint32_t n_views = 1,
@@ -56,7 +57,7 @@ struct vxrt_ctx {
     float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
     float ortho[2] = {10.0f, 10.0f};
     uint32_t frame_counter = 0;
-    int kernel_variant = 4;          // render: 4 = persistent waves, pool kernel for multi-view launches (default); 2 / 3 = one of
+    int kernel_variant = 4;          // render: 4 = persistent waves, kernel picked per launch (resolve_render_variant); 2 / 3 / 5 = one of
                                      // the two persistent kernels everywhere; 0 = wave state machine, 1 = straightforward
     unsigned persistent_waves = 4096;
     unsigned long long* d_stats = nullptr;
@@ -260,7 +261,7 @@ int vxrt_create(int device, vxrt_ctx** out)
         e = hipGetDeviceProperties(&prop, device);
         c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
         if (const char* v = getenv("VXRT_VARIANT"))                       // A/B of the render kernels (tools/)
-            if (atoi(v) >= 0 && atoi(v) <= 4)
+            if (atoi(v) >= 0 && atoi(v) <= 5)
                 c->kernel_variant = atoi(v);
         if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments only
             if (atoi(e) > 0 && atoi(e) <= 32)
@@ -291,10 +292,30 @@ int vxrt_destroy(vxrt_ctx* c)
     return VXRT_OK;
 }
 
+int vxrt_kernel_for_launch(const vxrt_ctx* c, uint32_t width, uint32_t height, const vxrt_render_flags* fl, uint32_t nviews)
+{
+    if (!c || !fl || fl->struct_size != sizeof(vxrt_render_flags))
+        return -1;
+    vxrt::RenderArgs A;
+    memset(&A, 0, sizeof(A));
+    A.width = width;
+    A.shadow = fl->shadow ? 1 : 0;
+    A.bounce_samples = fl->bounce_samples;
+    A.nviews = nviews;
+    // the launch grid's rows, as vxrt_render works them out
+    if (fl->checkerboard)
+        A.launch_rows = height >> 1;
+    else if (fl->strip_count > 1)
+        A.launch_rows = vxrt_compact_rows(height, fl->strip_rows > 0 ? fl->strip_rows : 16, fl->strip_count, fl->strip_index);
+    else
+        A.launch_rows = height;
+    return vxrt::resolve_render_variant(A, c->kernel_variant);
+}
+
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant > 4)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS) or 4 (default: 3 for multi-view launches, else 2)");
+    if (!c || variant < 0 || variant > 5)
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default: 3 for multi-view launches, else 2) or 5 (persistent, cold state in LDS, 5 waves per SIMD)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }
@@ -523,6 +544,12 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
         A.ortho_y = c->ortho[1];
     }
     A.light_dir = vxrt::f3{c->light_dir[0], c->light_dir[1], c->light_dir[2]};
+    {   // unit3() of vxrt_device.hpp on the host: v * (1 / sqrt(dot(v, v))), binary32 throughout, no contraction
+        const float lx = c->light_dir[0], ly = c->light_dir[1], lz = c->light_dir[2];
+        const float dd = lx * lx + ly * ly + lz * lz;
+        const float inv = 1.0f / sqrtf(dd);
+        A.light_unit = vxrt::f3{lx * inv, ly * inv, lz * inv};
+    }
     A.light_color = vxrt::f3{c->light_color[0], c->light_color[1], c->light_color[2]};
     A.ambient = vxrt::f3{c->ambient[0], c->ambient[1], c->ambient[2]};
     A.mode = fl->mode;

@@ -262,6 +262,7 @@ struct TraceResult {
     f3 pos;     // valid on hit
     f3 normal;  // step-direction convention; zero on a miss
     int vx, vy, vz;  // global voxel that ended the ray (valid on hit)
+    uint32_t ncode;  // wave tracer only: `normal` as its small code (normal_decode, vxrt_wave.hpp)
 };
 
 // Raytrace (VolumeRaytracer.cu:354-525), straightforward form.

@@ -84,7 +84,7 @@ __device__ f3 shade(const RenderArgs& A, uint32_t tx, uint32_t ty, f3 cam, f3 no
                     RayCounters& cnt, uint32_t& n_shadow, uint32_t& n_bounce)
 {
     const f3 L = A.light_dir;
-    f3 sray = unit3(L);
+    f3 sray = A.light_unit;
     f3 spos = position + sray * 0.01f;
     bool shadowed = false;
     if (A.shadow) {
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
 
     // shadow ray (Renderer.cu:97-102), entered by the whole wave
     const f3 L = A.light_dir;
-    const f3 sray = unit3(L);
+    const f3 sray = A.light_unit;
     bool shadowed = false;
     if (A.shadow) {
         TraceResult ts;
@@ -558,13 +558,33 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 }  // namespace vxrt
 
 #include "vxrt_persist.hpp"
+#include "vxrt_persist_lds.hpp"
 #include "vxrt_pool.hpp"
 #include "vxrt_batch_persist.hpp"
 
 namespace vxrt {
 
-// variant 0 = wave state machine, one lane per pixel; 1 = straightforward per-lane loops (A/B and cross-check);
-// 2 = persistent waves pulling pixels from a tile queue
+// The kernel a render launch runs: variant 0 = wave state machine, one lane per pixel; 1 = straightforward per-lane loops
+// (A/B and cross-check); 2 = persistent waves pulling pixels from a tile queue (k_render_persist); 3 = the same with the
+// pixel chains pooled in LDS (k_render_pool); 5 = k_render_persist with its cold state in LDS, 5 waves per SIMD
+// (k_render_persist_lds); 4 = the default, resolved per launch from measurements on one MI355X (profiles/r02_mechanisms_ab.md):
+//   * several views in one launch: 5 (5.12 Grays/s on the bench workload against 5.07 for the pool kernel and 4.88 for the
+//     pixel-per-lane kernel; +3 % on 4K frames, +1 % on the 16k world, equal within 0.3 % on the small configurations);
+//   * one view: 5 when the launch is large -- at least 4 M rays counting one shadow and one bounce ray per pixel where
+//     enabled (a 1080p frame with secondary rays: -1 % launched alone, +4.7 % with two frames in flight; 4K frames +3 % /
+//     +5 %) -- and 2 for small launches (1080p primary rays only: the 5-wave grid's longer ramp costs 8 % there).
+int resolve_render_variant(const RenderArgs& A, int variant)
+{
+    if (variant == 4) {
+        const unsigned long long rays = (unsigned long long)A.width * A.launch_rows *
+                                        (1ull + (A.shadow ? 1ull : 0ull) + (A.bounce_samples > 0 ? 1ull : 0ull));
+        variant = (A.nviews >= 2 || rays >= 4000000ull) ? 5 : 2;
+    }
+    if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))
+        variant = 2;  // the pool kernel packs the sample counter and the launch column into its slot words
+    return variant;
+}
+
 hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
 {
     // one wave per workgroup: no wave waits for a slower sibling before its slot is reused (+5 % measured)
@@ -575,17 +595,13 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
     if (grid.x == 0 || grid.y == 0)
         return hipSuccess;
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
-    // 4 = the default: the pool kernel for launches over several views (a wave then works through thousands of pixels and
-    // its pool runs in steady state: +2.8 % over the pixel-per-lane kernel), the pixel-per-lane kernel for one view (a
-    // wave's share of one 1080p frame is ~500 pixels, little more than the pool's fill and drain: -5 %)
-    if (variant == 4)
-        variant = A.nviews >= 2 ? 3 : 2;
-    if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))
-        variant = 2;  // the pool kernel packs the sample counter and the launch column into its slot words
-    if (variant == 2 || variant == 3) {
+    variant = resolve_render_variant(A, variant);
+    if (variant == 2 || variant == 3 || variant == 5) {
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
-        const unsigned waves = ntiles < A.persistent_waves ? (unsigned)ntiles : A.persistent_waves;
+        // persistent_waves = 4 per SIMD; variant 5's kernel is built for VXRT_PERSIST_LDS_OCC
+        const unsigned resident = variant == 5 ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST_LDS_OCC : A.persistent_waves;
+        const unsigned waves = ntiles < resident ? (unsigned)ntiles : resident;
         const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
             return e;
@@ -595,6 +611,8 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
     do {                                                                                     \
         if (variant == 3)                                                                    \
             hipLaunchKernelGGL((k_render_pool<S, B2, M>), g, b, 0, stream, A);               \
+        else if (variant == 5)                                                               \
+            hipLaunchKernelGGL((k_render_persist_lds<S, B2, M>), g, b, 0, stream, A);        \
         else                                                                                 \
             hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A);          \
     } while (0)
@@ -634,7 +652,8 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
     // default: persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the
     // persistent grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
-    if (variant == 2 && B.ticket && !B.dbg_trace && B.persistent_waves && B.n >= 8ull * 64ull * B.persistent_waves) {
+    if (variant >= 2 && B.ticket && !B.dbg_trace  // (render variants 3..5 are all 'persistent' for a batch)
+         && B.persistent_waves && B.n >= 8ull * 64ull * B.persistent_waves) {
         const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess)
             return e;

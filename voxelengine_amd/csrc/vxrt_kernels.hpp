@@ -64,6 +64,8 @@ struct RenderArgs {
     float4* accum;       // temporal accumulation history (vxrt_render_flags.d_accum), single-view launches only, or NULL
     int accum_reset;
     int want_hit_aov;  // some view of the launch has a hit-index AOV (the pool kernel keeps the voxel in the pixel's slot then)
+    f3 light_unit;  // normalize(light_dir), the shadow ray (Renderer.cu:97): the same IEEE operations, evaluated once on the host
+                    // (k_render_persist_lds; appended, so that the other kernels' argument layout is what it was)
 };
 
 // the per-view part of RenderArgs for a launch that renders several views of the same world

@@ -188,7 +188,6 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             T.max_steps = (m & 8u) ? 8 : kMaxSteps;
             T.last_ci = 0xFFFFFFFFu;
             T.total = 0;
-            T.hit_pos = mk3(0, 0, 0);
             T.ray_hit = false;
             T.out_code = 0u;
             T.bits = W.coarse_bits;

@@ -62,19 +62,29 @@ __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_
 #define VXRT_VOTE_BOX 4
 #endif
 
+// The "cold" part of a lane's ray -- everything only the parked phases, begin_ray and result touch (the probes never
+// do).  With LDS_COLD it lives in the wave's LDS block, one 64-lane column per field (conflict-free ds_read/ds_write,
+// pairs of fields per ds_read2st64), and costs no registers between phases: that is what lets the kernel that uses it
+// run 5 waves per SIMD (96 VGPRs) instead of 4.
+enum : int {
+    CF_MAX_STEPS = 0, CF_START_X, CF_START_Y, CF_START_Z, CF_ENTRY_CODE, CF_LAST_CI, CF_OUT_CODE, CF_TOTAL, CF_RAY_HIT,
+    CF_CHX, CF_CHY, CF_CHZ, CF_NC_AXIS, CF_C_CODE, CF_SLOT, CF_C_CI, CF_TRACER_FIELDS
+};
+
 // One lane's ray: Raytrace-level state (:359-384), the current DDARayTraversal walk (:178-232) and the coarse
-// results that outlive the coarse walk (:399-429,:438-488).  All members live in registers.
-template <bool STATS, bool MASKED_LOAD = false>
+// results that outlive the coarse walk (:399-429,:438-488).  All members live in registers, except that with LDS_COLD
+// the cold ones (marked) are never touched and their values live in LDS (`cold` = this lane's column).
+template <bool STATS, bool MASKED_LOAD = false, bool LDS_COLD = false>
 struct WaveTracer {
     // per-ray constants
     f3 d;                 // normalised direction
     float ivx, ivy, ivz;  // 1/(d or eps): the slab test's reciprocal (:127-129), and |iv| is the DDA's tDelta (:199-201)
-    int max_steps;
-    // Raytrace level
-    f3 start;
+    int max_steps;  // (cold)
+    // Raytrace level (cold).  With LDS_COLD hitPosition (:397,:426) is not kept: when the ray has ended it is `point` in
+    // voxel units, recomputed by result() with the same float operations on the same operands
+    f3 start, hit_pos;
     uint32_t entry_code, last_ci, out_code;
     int total;
-    f3 hit_pos;
     bool ray_hit;
     // current walk
     uint32_t st, fine, wf, w_code, skip;
@@ -84,14 +94,26 @@ struct WaveTracer {
     int up_x, up_y, up_z;              // per-ray: 1 where the direction component is positive (:195-197)
     float tn_x, tn_y, tn_z;
     int steps;  // stepsTaken; also the reference's loop index: an iteration continues exactly when a step is counted
-    // coarse results kept across the brick walk
+    // coarse results kept across the brick walk (cold)
     int chx, chy, chz, nc_axis;
     uint32_t c_code, slot, c_ci;  // c_ci: tiled index of the coarse HitCell (previous_cell compares it, :402-407)
     const uint32_t* bits;
     RayCounters cnt;
+    uint32_t* cold;  // LDS_COLD: &block[lane]; field F of this lane is cold[F * 64]
 
-    __device__ __forceinline__ void init(const WorldView& W)
+    // a cold field: the register member, or its LDS cell
+    __device__ __forceinline__ uint32_t cget(int f, uint32_t reg) const { return LDS_COLD ? cold[f * 64] : reg; }
+    __device__ __forceinline__ int cget(int f, int reg) const { return LDS_COLD ? (int)cold[f * 64] : reg; }
+    __device__ __forceinline__ float cget(int f, float reg) const { return LDS_COLD ? __uint_as_float(cold[f * 64]) : reg; }
+    __device__ __forceinline__ bool cget(int f, bool reg) const { return LDS_COLD ? cold[f * 64] != 0u : reg; }
+    __device__ __forceinline__ void cput(int f, uint32_t& reg, uint32_t v) { if (LDS_COLD) cold[f * 64] = v; else reg = v; }
+    __device__ __forceinline__ void cput(int f, int& reg, int v) { if (LDS_COLD) cold[f * 64] = (uint32_t)v; else reg = v; }
+    __device__ __forceinline__ void cput(int f, float& reg, float v) { if (LDS_COLD) cold[f * 64] = __float_as_uint(v); else reg = v; }
+    __device__ __forceinline__ void cput(int f, bool& reg, bool v) { if (LDS_COLD) cold[f * 64] = v ? 1u : 0u; else reg = v; }
+
+    __device__ __forceinline__ void init(const WorldView& W, uint32_t* cold_column = nullptr)
     {
+        cold = cold_column;
         st = ST_DONE;
         fine = wf = w_code = skip = 0u;
         d = mk3(1.0f, 0.0f, 0.0f);
@@ -175,29 +197,31 @@ struct WaveTracer {
         // tDelta = |1/d|, or inf for d == 0 (:199-201), is not kept: where d != 0 it is |iv| (the same quotient), and an
         // axis with d == 0 has tMax = inf, is never the smallest, and inf + anything stays inf -- so `tn + |iv|` is
         // the reference's `tMax + tDelta` in every case
-        max_steps = max_steps_;
         up_x = d.x > 0 ? 1 : 0;
         up_y = d.y > 0 ? 1 : 0;
         up_z = d.z > 0 ? 1 : 0;
-        start = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
-        entry_code = 0u;
-        if (!(start.x >= 0 && start.y >= 0 && start.z >= 0 && start.x < (float)W.cx && start.y < (float)W.cy &&
-              start.z < (float)W.cz)) {
+        f3 s0 = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
+        uint32_t ec = 0u;
+        if (!(s0.x >= 0 && s0.y >= 0 && s0.z >= 0 && s0.x < (float)W.cx && s0.y < (float)W.cy && s0.z < (float)W.cz)) {
             const float e = (float)1e-6;
             f3 p;
             uint32_t c;
-            if (slab(start, mk3(e, e, e), mk3(W.wmax_x, W.wmax_y, W.wmax_z), p, c)) {
-                start = p;
-                entry_code = c;
+            if (slab(s0, mk3(e, e, e), mk3(W.wmax_x, W.wmax_y, W.wmax_z), p, c)) {
+                s0 = p;
+                ec = c;
             }
         }
-        last_ci = 0xFFFFFFFFu;  // previous_cell as its tiled index (unique per cell); none yet
-        total = 0;
-        hit_pos = mk3(0, 0, 0);
-        ray_hit = false;
-        out_code = 0u;
+        cput(CF_MAX_STEPS, max_steps, max_steps_);
+        cput(CF_START_X, start.x, s0.x);
+        cput(CF_START_Y, start.y, s0.y);
+        cput(CF_START_Z, start.z, s0.z);
+        cput(CF_ENTRY_CODE, entry_code, ec);
+        cput(CF_LAST_CI, last_ci, 0xFFFFFFFFu);  // previous_cell as its tiled index (unique per cell); none yet
+        cput(CF_TOTAL, total, 0);
+        cput(CF_RAY_HIT, ray_hit, false);
+        cput(CF_OUT_CODE, out_code, 0u);
         bits = W.coarse_bits;
-        begin_walk(W, start, 0u);
+        begin_walk(W, s0, 0u);
         st = ST_WALK;
     }
 
@@ -208,32 +232,39 @@ struct WaveTracer {
         // (brick entry, coarse walk over, brick hit, brick miss), so every branch would be taken by somebody, and
         // the branchy form (three nested short-circuit compares, three ulp_steps with early returns, ...) paid
         // ~40 exec-mask round trips per execution for ~60 instructions of arithmetic.
-        total += steps;
+        const int total_ = cget(CF_TOTAL, total) + steps;
+        cput(CF_TOTAL, total, total_);
         const bool is_fine = fine != 0u;
-        const float fx = (float)chx, fy = (float)chy, fz = (float)chz;
+        const int hx = cget(CF_CHX, chx), hy = cget(CF_CHY, chy), hz = cget(CF_CHZ, chz);
+        const float fx = (float)hx, fy = (float)hy, fz = (float)hz;
         const float ox = fx * W.ff, oy = fy * W.ff, oz = fz * W.ff;  // the brick's origin in voxels
         // coarse walk: hitPosition = point * f (:397); brick walk: point + HitCell * f (:426)
-        hit_pos.x = is_fine ? point.x + ox : point.x * W.ff;
-        hit_pos.y = is_fine ? point.y + oy : point.y * W.ff;
-        hit_pos.z = is_fine ? point.z + oz : point.z * W.ff;
-        const uint32_t ci = c_ci;  // (computed by the tight-box phase that produced this coarse hit)
+        const f3 hp = mk3(is_fine ? point.x + ox : point.x * W.ff, is_fine ? point.y + oy : point.y * W.ff,
+                          is_fine ? point.z + oz : point.z * W.ff);
+        if (!LDS_COLD) {
+            hit_pos.x = hp.x;
+            hit_pos.y = hp.y;
+            hit_pos.z = hp.z;
+        }
+        const uint32_t ci = cget(CF_C_CI, c_ci);  // (computed by the tight-box phase that produced this coarse hit)
+        const uint32_t last_ = cget(CF_LAST_CI, last_ci);
         // coarse walk ended on an occupied cell that is not the previous_cell (:399-407): enter its brick
-        const bool enter = !is_fine && wf == WF_HIT && ci != last_ci;
+        const bool enter = !is_fine && wf == WF_HIT && ci != last_;
         const bool fine_hit = is_fine && (wf & WF_HIT) != 0u;  // :493-506
         const bool fine_miss = is_fine && (wf & WF_HIT) == 0u;  // restart the coarse walk just past the brick (:431-491)
-        last_ci = enter ? ci : last_ci;
+        cput(CF_LAST_CI, last_ci, enter ? ci : last_);
         if (STATS)
             cnt.brick_entries += enter ? 1u : 0u;
         // w_code = axis + 1 of the walk's last counted step; normal code = (axis+1) | 4*negative
         // (selects against 0, OR-ed: a chained `?:` over the three members is the selected-address trap, which
         // demoted the whole tracer to scratch memory and cost 60 % of the frame rate)
         const int up_last = (w_code == 1u ? up_x : 0) | (w_code == 2u ? up_y : 0) | (w_code == 3u ? up_z : 0);
-        const uint32_t hit_code = (steps == 0) ? c_code : (w_code + 4u - 4u * (uint32_t)up_last);
-        out_code = fine_hit ? hit_code : out_code;
-        ray_hit = fine_hit ? true : ray_hit;
+        const uint32_t hit_code = (steps == 0) ? cget(CF_C_CODE, c_code) : (w_code + 4u - 4u * (uint32_t)up_last);
+        cput(CF_OUT_CODE, out_code, fine_hit ? hit_code : cget(CF_OUT_CODE, out_code));
+        cput(CF_RAY_HIT, ray_hit, fine_hit ? true : cget(CF_RAY_HIT, ray_hit));
         // brick miss: start = hitPosition / f; if the brick walk left the brick and start is still inside HitCell,
         // nudge all three components one ulp along the ray, and if that is not enough snap one axis to NextCell
-        float sx = hit_pos.x * W.inv_f, sy = hit_pos.y * W.inv_f, sz = hit_pos.z * W.inv_f;
+        float sx = hp.x * W.inv_f, sy = hp.y * W.inv_f, sz = hp.z * W.inv_f;
         const bool same1 = (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
         const bool nudge = fine_miss & ((wf & WF_OOB) != 0u) & same1;
         const float ux = ulp_step(sx, d.x < 0), uy = ulp_step(sy, d.y < 0), uz = ulp_step(sz, d.z < 0);
@@ -243,10 +274,11 @@ struct WaveTracer {
         const bool snap = nudge & (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
         // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from the clamped HitCell by
         // one when the walk started on a far face (edge rule)
-        const int axis = nc_axis & 3;
-        const int ncx = chx + ((nc_axis >> 2) & 1) + (axis == 0 ? 2 * up_x - 1 : 0);
-        const int ncy = chy + ((nc_axis >> 3) & 1) + (axis == 1 ? 2 * up_y - 1 : 0);
-        const int ncz = chz + ((nc_axis >> 4) & 1) + (axis == 2 ? 2 * up_z - 1 : 0);
+        const int nca = cget(CF_NC_AXIS, nc_axis);
+        const int axis = nca & 3;
+        const int ncx = hx + ((nca >> 2) & 1) + (axis == 0 ? 2 * up_x - 1 : 0);
+        const int ncy = hy + ((nca >> 3) & 1) + (axis == 1 ? 2 * up_y - 1 : 0);
+        const int ncz = hz + ((nca >> 4) & 1) + (axis == 2 ? 2 * up_z - 1 : 0);
         const float gx = (float)ncx - sx, gy = (float)ncy - sy, gz = (float)ncz - sz;
         const float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
         const bool snap_x = (mx < my) & (mx < mz);               // :475-486, in the reference's order
@@ -255,18 +287,18 @@ struct WaveTracer {
         sx = (snap & snap_x) ? sx + gx : sx;  // (a branch around this rare case measured no better)
         sy = (snap & snap_y) ? sy + gy : sy;
         sz = (snap & snap_z) ? sz + gz : sz;
-        start.x = fine_miss ? sx : start.x;
-        start.y = fine_miss ? sy : start.y;
-        start.z = fine_miss ? sz : start.z;
-        const bool restart = fine_miss && total < max_steps;  // the while condition, checked only here (:386)
+        cput(CF_START_X, start.x, fine_miss ? sx : cget(CF_START_X, start.x));
+        cput(CF_START_Y, start.y, fine_miss ? sy : cget(CF_START_Y, start.y));
+        cput(CF_START_Z, start.z, fine_miss ? sz : cget(CF_START_Z, start.z));
+        const bool restart = fine_miss && total_ < cget(CF_MAX_STEPS, max_steps);  // the while condition, checked only here (:386)
         const bool go = enter | restart;
         // both continuations (enter the brick / restart the coarse walk) share ONE begin_walk: its three IEEE
         // divisions are the bulk of this phase
-        const uint32_t* const brick = W.pool + (size_t)slot * W.brick_words;
+        const uint32_t* const brick = W.pool + (size_t)cget(CF_SLOT, slot) * W.brick_words;
         bits = enter ? brick : (restart ? W.coarse_bits : bits);
         st = go ? (uint32_t)ST_WALK : (uint32_t)ST_DONE;
         if (go) {
-            const f3 ns = mk3(enter ? hit_pos.x - ox : sx, enter ? hit_pos.y - oy : sy, enter ? hit_pos.z - oz : sz);
+            const f3 ns = mk3(enter ? hp.x - ox : sx, enter ? hp.y - oy : sy, enter ? hp.z - oz : sz);
             begin_walk(W, ns, enter ? 1u : 0u);
         }
     }
@@ -295,17 +327,29 @@ struct WaveTracer {
         point.x = move_point ? bp.x : point.x;  // per component: a struct-valued ?: selects an ADDRESS (same trap)
         point.y = move_point ? bp.y : point.y;
         point.z = move_point ? bp.z : point.z;
-        chx = box_hit ? qx : chx;
-        chy = box_hit ? qy : chy;
-        chz = box_hit ? qz : chz;
-        c_code = box_hit ? bc : c_code;
-        slot = box_hit ? meta.x : slot;
-        c_ci = box_hit ? idx : c_ci;
+        if (!LDS_COLD) {
+            chx = box_hit ? qx : chx;
+            chy = box_hit ? qy : chy;
+            chz = box_hit ? qz : chz;
+            c_code = box_hit ? bc : c_code;
+            slot = box_hit ? meta.x : slot;
+            c_ci = box_hit ? idx : c_ci;
+        }
         // the exit iteration's extra advance (:290-322) only matters through NextCell: keep its axis (bits 0-1)
         // and, per axis, whether the unclamped cell sits one past the clamped HitCell (bits 2-4; edge rule only)
         const int axis = (tn_x < tn_y && tn_x < tn_z) ? 0 : ((tn_y <= tn_x && tn_y < tn_z) ? 1 : 2);
         const int packed = axis | ((cell_x - qx) << 2) | ((cell_y - qy) << 3) | ((cell_z - qz) << 4);
-        nc_axis = box_hit ? packed : nc_axis;
+        if (!LDS_COLD)
+            nc_axis = box_hit ? packed : nc_axis;
+        if (LDS_COLD && box_hit) {  // (the phase runs under the ST_BOX lanes' exec mask anyway: plain stores)
+            cold[CF_CHX * 64] = (uint32_t)qx;
+            cold[CF_CHY * 64] = (uint32_t)qy;
+            cold[CF_CHZ * 64] = (uint32_t)qz;
+            cold[CF_C_CODE * 64] = bc;
+            cold[CF_SLOT * 64] = meta.x;
+            cold[CF_C_CI * 64] = idx;
+            cold[CF_NC_AXIS * 64] = (uint32_t)packed;
+        }
     }
 
     // hot path: probe the current cell and advance, predicated on st == ST_WALK; executed by every lane.  Lane
@@ -522,28 +566,50 @@ struct WaveTracer {
     // Raytrace's epilogue (:514-523)
     __device__ __forceinline__ void result(const WorldView& W, TraceResult& out) const
     {
-        out.hit = ray_hit;
-        out.steps = total;
-        out.normal = normal_decode(out_code);
-        out.pos = hit_pos;
-        // brick HitCell = the clamped cell that was probed last (the walk does not advance past a hit)
-        out.vx = chx * W.f + min(cell_x, W.f - 1);
-        out.vy = chy * W.f + min(cell_y, W.f - 1);
-        out.vz = chz * W.f + min(cell_z, W.f - 1);
-        if (ray_hit && total == 0) {
-            out.pos = mk3(start.x * W.ff, start.y * W.ff, start.z * W.ff);
-            out.normal = normal_decode(entry_code);
+        if (!LDS_COLD) {
+            out.hit = ray_hit;
+            out.steps = total;
+            out.ncode = 0u;  // (register mode: the callers read entry_code / out_code themselves)
+            out.normal = normal_decode(out_code);
+            out.pos = hit_pos;
+            out.vx = chx * W.f + min(cell_x, W.f - 1);
+            out.vy = chy * W.f + min(cell_y, W.f - 1);
+            out.vz = chz * W.f + min(cell_z, W.f - 1);
+            if (ray_hit && total == 0) {
+                out.pos = mk3(start.x * W.ff, start.y * W.ff, start.z * W.ff);
+                out.normal = normal_decode(entry_code);
+            }
+            return;
         }
+        const bool hit = cget(CF_RAY_HIT, ray_hit);
+        const int total_ = cget(CF_TOTAL, total);
+        const int hx = cget(CF_CHX, chx), hy = cget(CF_CHY, chy), hz = cget(CF_CHZ, chz);
+        out.hit = hit;
+        out.steps = total_;
+        // hitPosition of the walk that ended the ray, as phase_end computed it (the same operands, the same operations)
+        const bool is_fine = fine != 0u;
+        const float ox = (float)hx * W.ff, oy = (float)hy * W.ff, oz = (float)hz * W.ff;
+        out.pos = mk3(is_fine ? point.x + ox : point.x * W.ff, is_fine ? point.y + oy : point.y * W.ff,
+                      is_fine ? point.z + oz : point.z * W.ff);
+        // brick HitCell = the clamped cell that was probed last (the walk does not advance past a hit)
+        out.vx = hx * W.f + min(cell_x, W.f - 1);
+        out.vy = hy * W.f + min(cell_y, W.f - 1);
+        out.vz = hz * W.f + min(cell_z, W.f - 1);
+        const bool at_entry = hit && total_ == 0;
+        out.ncode = at_entry ? cget(CF_ENTRY_CODE, entry_code) : cget(CF_OUT_CODE, out_code);
+        out.normal = normal_decode(out.ncode);
+        if (at_entry)
+            out.pos = mk3(cget(CF_START_X, start.x) * W.ff, cget(CF_START_Y, start.y) * W.ff, cget(CF_START_Z, start.z) * W.ff);
     }
 };
 
 // one ray per lane, entered by the whole wave at a converged point
-template <bool STATS, bool MASKED_LOAD = false>
+template <bool STATS, bool MASKED_LOAD = false, bool LDS_COLD = false>
 __device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
-                           TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr)
+                           TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr, uint32_t* cold_column = nullptr)
 {
-    WaveTracer<STATS, MASKED_LOAD> T;
-    T.init(W);
+    WaveTracer<STATS, MASKED_LOAD, LDS_COLD> T;
+    T.init(W, cold_column);
     if (active)
         T.begin_ray(W, origin, ray, max_steps);
     for (;;) {

@@ -287,9 +287,21 @@ class Context:
     def set_kernel_variant(self, variant: int) -> None:
         """0 = wave-level state machine, 1 = straightforward per-lane loops (A/B, cross-check), 2 = persistent
         waves with a pixel queue, 3 = persistent waves with the pixel chains pooled in LDS, 4 = default (3 for
-        multi-view launches, 2 for single-view ones)."""
+        multi-view launches, 2 for single-view ones), 5 = persistent waves with the cold state (tracer fields only the parked
+        phases touch, the pixel's chain state) in LDS, 5 waves per SIMD."""
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
         self.kernel_variant = int(variant)
+
+    KERNEL_NAMES = {0: "k_render_wave", 1: "k_render", 2: "k_render_persist", 3: "k_render_pool", 5: "k_render_persist_lds"}
+
+    def kernel_for_launch(self, width: int, height: int, opts: "RenderOptions | None" = None, nviews: int = 0) -> int:
+        """The kernel (0, 1, 2, 3 or 5) a RenderScreen (nviews = 0) or RenderViews launch of this shape runs under the
+        current variant (vxrt_kernel_for_launch); KERNEL_NAMES maps it to the kernel's name in a profile."""
+        fl = self._flags(opts, None)
+        k = int(self._L.vxrt_kernel_for_launch(self._h, int(width), int(height), C.byref(fl), int(nviews)))
+        if k < 0:
+            raise N.VxrtError("vxrt_kernel_for_launch: bad arguments")
+        return k
 
     def synchronize(self) -> None:
         N.check(self._L.vxrt_synchronize(self._h))
