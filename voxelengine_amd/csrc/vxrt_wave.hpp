@@ -66,9 +66,11 @@ __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_
 // do).  With LDS_COLD it lives in the wave's LDS block, one 64-lane column per field (conflict-free ds_read/ds_write,
 // pairs of fields per ds_read2st64), and costs no registers between phases: that is what lets the kernel that uses it
 // run 5 waves per SIMD (96 VGPRs) instead of 4.
+// In LDS the small ones share a word: CF_RAY_CODES = entry_code (3 bits) | out_code << 3 | ray_hit << 6 | max_steps << 7,
+// CF_BOX_CODES = c_code (3 bits) | nc_axis << 3 (both written by the tight-box phase only).
 enum : int {
-    CF_MAX_STEPS = 0, CF_START_X, CF_START_Y, CF_START_Z, CF_ENTRY_CODE, CF_LAST_CI, CF_OUT_CODE, CF_TOTAL, CF_RAY_HIT,
-    CF_CHX, CF_CHY, CF_CHZ, CF_NC_AXIS, CF_C_CODE, CF_SLOT, CF_C_CI, CF_TRACER_FIELDS
+    CF_RAY_CODES = 0, CF_START_X, CF_START_Y, CF_START_Z, CF_LAST_CI, CF_TOTAL,
+    CF_CHX, CF_CHY, CF_CHZ, CF_BOX_CODES, CF_SLOT, CF_C_CI, CF_TRACER_FIELDS
 };
 
 // One lane's ray: Raytrace-level state (:359-384), the current DDARayTraversal walk (:178-232) and the coarse
@@ -211,15 +213,21 @@ struct WaveTracer {
                 ec = c;
             }
         }
-        cput(CF_MAX_STEPS, max_steps, max_steps_);
+        if (LDS_COLD)
+            cold[CF_RAY_CODES * 64] = ec | ((uint32_t)max_steps_ << 7);  // out_code = 0, ray_hit = false
+        else
+            max_steps = max_steps_;
         cput(CF_START_X, start.x, s0.x);
         cput(CF_START_Y, start.y, s0.y);
         cput(CF_START_Z, start.z, s0.z);
-        cput(CF_ENTRY_CODE, entry_code, ec);
+        if (!LDS_COLD)
+            entry_code = ec;
         cput(CF_LAST_CI, last_ci, 0xFFFFFFFFu);  // previous_cell as its tiled index (unique per cell); none yet
         cput(CF_TOTAL, total, 0);
-        cput(CF_RAY_HIT, ray_hit, false);
-        cput(CF_OUT_CODE, out_code, 0u);
+        if (!LDS_COLD) {
+            ray_hit = false;
+            out_code = 0u;
+        }
         bits = W.coarse_bits;
         begin_walk(W, s0, 0u);
         st = ST_WALK;
@@ -259,9 +267,15 @@ struct WaveTracer {
         // (selects against 0, OR-ed: a chained `?:` over the three members is the selected-address trap, which
         // demoted the whole tracer to scratch memory and cost 60 % of the frame rate)
         const int up_last = (w_code == 1u ? up_x : 0) | (w_code == 2u ? up_y : 0) | (w_code == 3u ? up_z : 0);
-        const uint32_t hit_code = (steps == 0) ? cget(CF_C_CODE, c_code) : (w_code + 4u - 4u * (uint32_t)up_last);
-        cput(CF_OUT_CODE, out_code, fine_hit ? hit_code : cget(CF_OUT_CODE, out_code));
-        cput(CF_RAY_HIT, ray_hit, fine_hit ? true : cget(CF_RAY_HIT, ray_hit));
+        const uint32_t box_codes = LDS_COLD ? cold[CF_BOX_CODES * 64] : 0u;
+        const uint32_t ray_codes = LDS_COLD ? cold[CF_RAY_CODES * 64] : 0u;
+        const uint32_t hit_code = (steps == 0) ? (LDS_COLD ? (box_codes & 7u) : c_code) : (w_code + 4u - 4u * (uint32_t)up_last);
+        if (LDS_COLD) {
+            cold[CF_RAY_CODES * 64] = fine_hit ? ((ray_codes & ~0x78u) | (hit_code << 3) | 0x40u) : ray_codes;
+        } else {
+            out_code = fine_hit ? hit_code : out_code;
+            ray_hit = fine_hit ? true : ray_hit;
+        }
         // brick miss: start = hitPosition / f; if the brick walk left the brick and start is still inside HitCell,
         // nudge all three components one ulp along the ray, and if that is not enough snap one axis to NextCell
         float sx = hp.x * W.inv_f, sy = hp.y * W.inv_f, sz = hp.z * W.inv_f;
@@ -274,7 +288,7 @@ struct WaveTracer {
         const bool snap = nudge & (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
         // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from the clamped HitCell by
         // one when the walk started on a far face (edge rule)
-        const int nca = cget(CF_NC_AXIS, nc_axis);
+        const int nca = LDS_COLD ? (int)(box_codes >> 3) : nc_axis;
         const int axis = nca & 3;
         const int ncx = hx + ((nca >> 2) & 1) + (axis == 0 ? 2 * up_x - 1 : 0);
         const int ncy = hy + ((nca >> 3) & 1) + (axis == 1 ? 2 * up_y - 1 : 0);
@@ -290,7 +304,7 @@ struct WaveTracer {
         cput(CF_START_X, start.x, fine_miss ? sx : cget(CF_START_X, start.x));
         cput(CF_START_Y, start.y, fine_miss ? sy : cget(CF_START_Y, start.y));
         cput(CF_START_Z, start.z, fine_miss ? sz : cget(CF_START_Z, start.z));
-        const bool restart = fine_miss && total_ < cget(CF_MAX_STEPS, max_steps);  // the while condition, checked only here (:386)
+        const bool restart = fine_miss && total_ < (LDS_COLD ? (int)(ray_codes >> 7) : max_steps);  // the while condition, checked only here (:386)
         const bool go = enter | restart;
         // both continuations (enter the brick / restart the coarse walk) share ONE begin_walk: its three IEEE
         // divisions are the bulk of this phase
@@ -345,10 +359,9 @@ struct WaveTracer {
             cold[CF_CHX * 64] = (uint32_t)qx;
             cold[CF_CHY * 64] = (uint32_t)qy;
             cold[CF_CHZ * 64] = (uint32_t)qz;
-            cold[CF_C_CODE * 64] = bc;
+            cold[CF_BOX_CODES * 64] = bc | ((uint32_t)packed << 3);
             cold[CF_SLOT * 64] = meta.x;
             cold[CF_C_CI * 64] = idx;
-            cold[CF_NC_AXIS * 64] = (uint32_t)packed;
         }
     }
 
@@ -581,7 +594,8 @@ struct WaveTracer {
             }
             return;
         }
-        const bool hit = cget(CF_RAY_HIT, ray_hit);
+        const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
+        const bool hit = (ray_codes & 0x40u) != 0u;
         const int total_ = cget(CF_TOTAL, total);
         const int hx = cget(CF_CHX, chx), hy = cget(CF_CHY, chy), hz = cget(CF_CHZ, chz);
         out.hit = hit;
@@ -596,7 +610,7 @@ struct WaveTracer {
         out.vy = hy * W.f + min(cell_y, W.f - 1);
         out.vz = hz * W.f + min(cell_z, W.f - 1);
         const bool at_entry = hit && total_ == 0;
-        out.ncode = at_entry ? cget(CF_ENTRY_CODE, entry_code) : cget(CF_OUT_CODE, out_code);
+        out.ncode = at_entry ? (ray_codes & 7u) : ((ray_codes >> 3) & 7u);
         out.normal = normal_decode(out.ncode);
         if (at_entry)
             out.pos = mk3(cget(CF_START_X, start.x) * W.ff, cget(CF_START_Y, start.y) * W.ff, cget(CF_START_Z, start.z) * W.ff);
