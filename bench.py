@@ -364,9 +364,9 @@ def run(args):
                          "convention": "achieved = algorithmic bytes (SURVEY.md 8d: 28 B per coarse probe, 24 B per brick entry, "
                                        "4 B per brick probe, 4 B per pixel) / launch time; not measured HBM traffic",
                          "traffic_frac": None if traffic is None else round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
-                         "physical_bound": "instruction issue per wavefront at 4 waves/SIMD (divergent traversal); "
+                         "physical_bound": "instruction issue per wavefront at 5 waves/SIMD (divergent traversal); "
                                            "issue_utilisation = instructions issued per SIMD cycle against the rate the same "
-                                           "instruction mix reaches in profiles/r02_issue_rate_ubench.txt",
+                                           "instruction mix reaches in profiles/r02b_issue_rate_ubench.txt",
                          "issue_utilisation": issue},
         }
         if rehearse or args.force_gather:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
