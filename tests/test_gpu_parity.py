@@ -557,3 +557,28 @@ def test_errors_are_reported_not_swallowed(eng, vxo):
     with pytest.raises(vx.VxrtError):
         c2.build_world(0, 128, 128, 128, 32)               # coarse dims not multiples of 8
     c2.close()
+
+
+def test_kernel_for_launch_reports_the_policy(eng, vxo):
+    """vxrt_kernel_for_launch: what the default (variant 4) resolves to per launch shape, and that a forced variant is
+    reported as itself (the pool kernel falls back to the pixel-per-lane kernel beyond its packed sample counter)."""
+    vx, ctx, torch = eng
+    default = ctx.kernel_variant
+    try:
+        ctx.set_kernel_variant(4)
+        shaded = vx.RenderOptions(shadow=True, bounce_samples=1)
+        assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 5       # several views
+        assert ctx.kernel_for_launch(1920, 1080, shaded) == 5                   # 6.2 M rays
+        assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions()) == 2       # 2.1 M rays, primary only
+        assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions()) == 5       # 8.3 M rays
+        assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions(shadow=True, checkerboard=True)) == 2  # half the rows
+        assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions(shadow=True, strip_rows=16, strip_count=8, strip_index=3,
+                                                                  compact=True)) == 2   # a 1/8 shard of a 4K frame
+        for v in (0, 1, 2, 3, 5):
+            ctx.set_kernel_variant(v)
+            assert ctx.kernel_for_launch(640, 480, shaded) == v
+        ctx.set_kernel_variant(3)
+        assert ctx.kernel_for_launch(640, 480, vx.RenderOptions(bounce_samples=2000)) == 2
+        assert ctx.KERNEL_NAMES[5] == "k_render_persist_lds"
+    finally:
+        ctx.set_kernel_variant(default)
