@@ -549,6 +549,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
         const float dd = lx * lx + ly * ly + lz * lz;
         const float inv = 1.0f / sqrtf(dd);
         A.light_unit = vxrt::f3{lx * inv, ly * inv, lz * inv};
+        A.light_step = vxrt::f3{A.light_unit.x * 0.01f, A.light_unit.y * 0.01f, A.light_unit.z * 0.01f};
     }
     A.light_color = vxrt::f3{c->light_color[0], c->light_color[1], c->light_color[2]};
     A.ambient = vxrt::f3{c->ambient[0], c->ambient[1], c->ambient[2]};
@@ -556,6 +557,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     A.checkerboard = fl->checkerboard ? 1 : 0;
     A.shadow = fl->shadow ? 1 : 0;
     A.bounce_samples = fl->bounce_samples < 0 ? 0 : fl->bounce_samples;
+    A.bounce_samples_f = (float)A.bounce_samples;
     A.bounce_all_hits = fl->bounce_all_hits ? 1 : 0;
     A.bounce_depth = fl->bounce_depth >= 2 ? 2 : 1;
     A.ortho = fl->ortho ? 1 : 0;

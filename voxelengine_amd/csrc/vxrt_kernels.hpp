@@ -66,6 +66,8 @@ struct RenderArgs {
     int want_hit_aov;  // some view of the launch has a hit-index AOV (the pool kernel keeps the voxel in the pixel's slot then)
     f3 light_unit;  // normalize(light_dir), the shadow ray (Renderer.cu:97): the same IEEE operations, evaluated once on the host
                     // (k_render_persist_lds; appended, so that the other kernels' argument layout is what it was)
+    f3 light_step;           // light_unit * 0.01f (the shadow ray's offset, Renderer.cu:97)
+    float bounce_samples_f;  // (float)bounce_samples
 };
 
 // the per-view part of RenderArgs for a launch that renders several views of the same world

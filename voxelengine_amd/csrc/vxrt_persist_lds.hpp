@@ -41,7 +41,6 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
     const WorldView& W = A.W;
     const int lane = threadIdx.x & 63;
     uint32_t* const PX = &cold_block[CF_TRACER_FIELDS * 64 + lane];  // this lane's column of the pixel fields
-    const unsigned long long lane_below = (1ull << lane) - 1ull;
     // (staging the launch's per-view parameters in LDS instead of gathering them from L2 in the ray-finished phase
     // was measured: -0.3 %, the loads are not what that phase waits for)
     auto lane_view = [&](uint32_t v) -> LaneView {
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
                     } else if (A.shadow) {
                         c_shadow = true;
                         launch = true;  // Renderer.cu:97-102
-                        l_origin = position + sray * 0.01f;
+                        l_origin = position + A.light_step;  // sray * 0.01f, the product evaluated on the host
                         l_dir = sray;
                         l_max = kMaxSteps;
                         stage = PX_SHADOW;
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
                         if (sample < A.bounce_samples) {
                             bounce = true;
                         } else {
-                            occl /= (float)A.bounce_samples;
+                            occl /= A.bounce_samples_f;
                             PX_LD_COL();
                             color = color * occl;
                             PX_ST_COL();
@@ -346,7 +345,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
                 }
                 const uint32_t avail = 64u - tile_used;
                 const bool wants = ((want >> lane) & 1ull) != 0ull;
-                const uint32_t rank = (uint32_t)__popcll(want & lane_below);
+                // this lane's rank among the asking lanes: v_mbcnt counts the mask's bits below the lane (no 64-bit lane mask kept)
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)want, 0u));
                 if (wants && rank < avail) {
                     const uint32_t p = tile_used + rank;
                     px_tx = (tile % ntx) * 8u + (p & 7u);
