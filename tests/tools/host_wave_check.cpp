@@ -18,16 +18,29 @@ int main(int argc, char** argv)
     for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
         if (rand() / (double)RAND_MAX < dens) { uint64_t i = vxo_sample_index64(x, y, z, S, S); dense[i >> 5] |= 1u << (i & 31); }
     vxo_world* w = vxo_build_brickmap(dense.data(), S, S, S, f);
+    // the oracle's tables are in the reference's tiled order; the tracer reads the HBM order (x-fastest linear, both
+    // levels): re-order on the host what the library re-orders on the device (vxrt_worldgen.hip)
+    const int cx = w->cdims[0], cy = w->cdims[1], cz = w->cdims[2];
     std::vector<uint2> meta(w->ncells);
-    for (uint64_t i = 0; i < w->ncells; ++i) {
+    std::vector<uint32_t> coarse((w->ncells + 31) / 32, 0u);
+    for (int z = 0; z < cz; ++z) for (int y = 0; y < cy; ++y) for (int x = 0; x < cx; ++x) {
+        const uint64_t t = ref_tiled_index(x, y, z, cx / 8, cy / 8), i = (uint64_t)x + (uint64_t)cx * (y + (uint64_t)cy * z);
         uint32_t p = 0;
-        if (w->brick_slot[i] != VXO_EMPTY_SLOT) for (int k = 0; k < 6; ++k) p |= (uint32_t)(int)w->bounds[i * 6 + k] << (5 * k);
-        meta[i] = make_uint2(w->brick_slot[i], p);
+        if (w->brick_slot[t] != VXO_EMPTY_SLOT) for (int k = 0; k < 6; ++k) p |= (uint32_t)(int)w->bounds[t * 6 + k] << (5 * k);
+        meta[i] = make_uint2(w->brick_slot[t], p);
+        if ((w->coarse_bits[t >> 5] >> (t & 31)) & 1u) coarse[i >> 5] |= 1u << (i & 31);
     }
+    const uint32_t bw = f * f * f / 32;
+    std::vector<uint32_t> pool((size_t)w->nslots * bw, 0u);
+    for (uint64_t s = 0; s < w->nslots; ++s)
+        for (int z = 0; z < f; ++z) for (int y = 0; y < f; ++y) for (int x = 0; x < f; ++x) {
+            const uint32_t t = ref_tiled_index(x, y, z, f / 8, f / 8), i = (uint32_t)(x + f * (y + f * z));
+            if ((w->pool[s * bw + (t >> 5)] >> (t & 31)) & 1u) pool[s * bw + (i >> 5)] |= 1u << (i & 31);
+        }
     WorldView W{};
-    W.coarse_bits = w->coarse_bits; W.cell_meta = meta.data(); W.pool = w->pool;
-    W.cx = w->cdims[0]; W.cy = w->cdims[1]; W.cz = w->cdims[2]; W.ctw = W.cx / 8; W.ctwh = W.ctw * (W.cy / 8);
-    W.f = f; W.ftw = f / 8; W.ftwh = W.ftw * W.ftw; W.brick_words = f * f * f / 32; W.ff = (float)f; W.inv_f = 1.0f / f;
+    W.coarse_bits = coarse.data(); W.cell_meta = meta.data(); W.pool = pool.data();
+    W.cx = cx; W.cy = cy; W.cz = cz; W.c_row = cx; W.c_slice = cx * cy;
+    W.f = f; W.f_row = f; W.f_slice = f * f; W.brick_words = bw; W.ff = (float)f; W.inv_f = 1.0f / f;
     W.wmax_x = (float)((double)W.cx - 1e-6); W.wmax_y = (float)((double)W.cy - 1e-6); W.wmax_z = (float)((double)W.cz - 1e-6);
     W.X = S; W.Y = S;
     int bad = 0;

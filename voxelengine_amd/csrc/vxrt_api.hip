@@ -24,6 +24,11 @@ void launch_deinterleave(const void* shards, unsigned long long shard_stride_byt
                          uint32_t height, uint32_t strip_rows, uint32_t strip_count, hipStream_t stream, uint32_t n_views = 1,
                          unsigned long long view_stride_bytes = 0, unsigned long long fb_stride_bytes = 0);
 int build_world_on_device(struct ::vxrt_ctx* ctx, int generator, int X, int Y, int Z, int factor);
+// re-ordering between the reference's tiled bit order (the C ABI's and the file's) and the HBM order (vxrt_worldgen.hip)
+hipError_t layout_bits(const uint32_t* src, uint32_t* dst, const int cd[3], bool to_hbm);
+hipError_t layout_meta(const uint2* src, uint2* dst, const int cd[3], bool to_hbm);
+hipError_t layout_bricks(const uint32_t* src, uint32_t* dst, uint64_t nbricks, int f, bool to_hbm);  // src == dst: in place
+hipError_t chunk_tables(uint2* meta, uint32_t* coarse, const uint2* d_chunk_meta, int tx, int ty, int tz, int cx, int cy);
 }  // namespace vxrt
 
 static thread_local std::string g_last_error = "";
@@ -104,9 +109,10 @@ int check_shape(int factor, const int cd[3])
         return fail(VXRT_ERR_INVALID, "factor must be 8, 16 or 32");
     for (int a = 0; a < 3; ++a)
         if (cd[a] <= 0 || cd[a] % 8 != 0 || cd[a] > 65535)
-            return fail(VXRT_ERR_INVALID, "coarse dimensions must be positive multiples of 8 (tiled-linear layout)");
-    if ((uint64_t)(cd[0] / 8) * (uint64_t)(cd[1] / 8) >= (1ull << 24) || (uint64_t)cd[0] * cd[1] * cd[2] >= (1ull << 32))
-        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit tiled indices");
+            return fail(VXRT_ERR_INVALID, "coarse dimensions must be positive multiples of 8 (the tables' tiled order)");
+    // cell_index(): 24-bit multiply-adds on the strides cx and cx * cy, 32-bit cell indices
+    if ((uint64_t)cd[0] * (uint64_t)cd[1] >= (1ull << 24) || (uint64_t)cd[0] * cd[1] * cd[2] >= (1ull << 32))
+        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit cell indices (cx * cy must stay below 2^24)");
     return VXRT_OK;
 }
 
@@ -119,11 +125,11 @@ void fill_view(vxrt_ctx* c, int factor, const int cd[3])
     v.cx = cd[0];
     v.cy = cd[1];
     v.cz = cd[2];
-    v.ctw = cd[0] / 8;
-    v.ctwh = (cd[0] / 8) * (cd[1] / 8);
+    v.c_row = cd[0];
+    v.c_slice = cd[0] * cd[1];
     v.f = factor;
-    v.ftw = factor / 8;
-    v.ftwh = (factor / 8) * (factor / 8);
+    v.f_row = factor;
+    v.f_slice = factor * factor;
     v.brick_words = (uint32_t)(factor * factor * factor / 32);
     v.ff = (float)factor;
     v.inv_f = 1.0f / (float)factor;
@@ -367,10 +373,33 @@ int vxrt_upload_world(vxrt_ctx* c, const vxrt_world_desc* d)
     if (rc)
         return rc;
     const uint64_t bw = (uint64_t)f * f * f / 32;
-    VX_HIP(hipMemcpy(c->d_coarse, d->coarse_bits, ((ncells + 31) / 32) * sizeof(uint32_t), hipMemcpyHostToDevice));
-    VX_HIP(hipMemcpy(c->d_meta, meta.data(), ncells * sizeof(uint2), hipMemcpyHostToDevice));
-    if (d->nslots)
-        VX_HIP(hipMemcpy(c->d_pool, d->pool, d->nslots * bw * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the tables arrive in the reference's tiled order and are re-ordered on the device into the HBM order
+    const uint64_t coarse_bytes = ((ncells + 31) / 32) * sizeof(uint32_t);
+    uint32_t* t_coarse = nullptr;
+    uint2* t_meta = nullptr;
+    hipError_t e = hipMalloc((void**)&t_coarse, coarse_bytes);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t_meta, ncells * sizeof(uint2));
+    if (e == hipSuccess)
+        e = hipMemcpy(t_coarse, d->coarse_bits, coarse_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(t_meta, meta.data(), ncells * sizeof(uint2), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = vxrt::layout_bits(t_coarse, c->d_coarse, cd, true);
+    if (e == hipSuccess)
+        e = vxrt::layout_meta(t_meta, c->d_meta, cd, true);
+    if (e == hipSuccess && d->nslots)
+        e = hipMemcpy(c->d_pool, d->pool, d->nslots * bw * sizeof(uint32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && d->nslots)
+        e = vxrt::layout_bricks(c->d_pool, c->d_pool, d->nslots, f, true);
+    if (e == hipSuccess)
+        e = hipDeviceSynchronize();
+    (void)hipFree(t_coarse);
+    (void)hipFree(t_meta);
+    if (e != hipSuccess) {
+        vxrt::free_world(c);
+        return fail(VXRT_ERR_HIP, std::string("world upload: ") + hipGetErrorString(e));
+    }
     c->nslots = d->nslots;
     vxrt::fill_view(c, f, cd);
     c->has_world = true;
@@ -409,9 +438,39 @@ int vxrt_download_world(vxrt_ctx* c, uint32_t* coarse_bits, uint32_t* brick_slot
         return fail(VXRT_ERR_NO_WORLD, "no world resident");
     VX_HIP(hipSetDevice(c->device));
     VX_HIP(hipDeviceSynchronize());
-    VX_HIP(hipMemcpy(coarse_bits, c->d_coarse, ((c->ncells + 31) / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // back into the reference's tiled order, through device temporaries (the pool in pieces of at most 64 MiB)
+    const int cd[3] = {c->view.cx, c->view.cy, c->view.cz};
+    const uint64_t coarse_bytes = ((c->ncells + 31) / 32) * sizeof(uint32_t);
+    const uint64_t bw = c->view.brick_words;
+    const uint64_t piece = std::max<uint64_t>(1, (64ull << 20) / (bw * 4));  // bricks per piece
+    uint32_t *t_coarse = nullptr, *t_pool = nullptr;
+    uint2* t_meta = nullptr;
     std::vector<uint2> meta(c->ncells);
-    VX_HIP(hipMemcpy(meta.data(), c->d_meta, c->ncells * sizeof(uint2), hipMemcpyDeviceToHost));
+    hipError_t e = hipMalloc((void**)&t_coarse, coarse_bytes);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&t_meta, c->ncells * sizeof(uint2));
+    if (e == hipSuccess)
+        e = vxrt::layout_bits(c->d_coarse, t_coarse, cd, false);
+    if (e == hipSuccess)
+        e = vxrt::layout_meta(c->d_meta, t_meta, cd, false);
+    if (e == hipSuccess)
+        e = hipMemcpy(coarse_bits, t_coarse, coarse_bytes, hipMemcpyDeviceToHost);
+    if (e == hipSuccess)
+        e = hipMemcpy(meta.data(), t_meta, c->ncells * sizeof(uint2), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && pool && c->nslots) {
+        e = hipMalloc((void**)&t_pool, std::min<uint64_t>(piece, c->nslots) * bw * 4);
+        for (uint64_t at = 0; e == hipSuccess && at < c->nslots; at += piece) {
+            const uint64_t n = std::min<uint64_t>(piece, c->nslots - at);
+            e = vxrt::layout_bricks(c->d_pool + at * bw, t_pool, n, c->view.f, false);
+            if (e == hipSuccess)
+                e = hipMemcpy(pool + at * bw, t_pool, n * bw * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    (void)hipFree(t_coarse);
+    (void)hipFree(t_meta);
+    (void)hipFree(t_pool);
+    if (e != hipSuccess)
+        return fail(VXRT_ERR_HIP, std::string("world download: ") + hipGetErrorString(e));
     for (uint64_t i = 0; i < c->ncells; ++i) {
         brick_slot[i] = meta[i].x;
         float* b = bounds + i * 6;
@@ -423,8 +482,6 @@ int vxrt_download_world(vxrt_ctx* c, uint32_t* coarse_bits, uint32_t* brick_slot
                 b[k] = (float)((meta[i].y >> (5 * k)) & 31u);
         }
     }
-    if (pool && c->nslots)
-        VX_HIP(hipMemcpy(pool, c->d_pool, c->nslots * c->view.brick_words * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return VXRT_OK;
 }
 
@@ -974,14 +1031,33 @@ int vxrt_save_world(vxrt_ctx* c, const char* path)
         return fail(VXRT_ERR_INVALID, std::string(path) + ": cannot create");
     if (fwrite(&h, sizeof(h), 1, fc.f) != 1)
         return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed");
+    // the file holds the tables in the reference's tiled order: re-ordered on the device, then streamed out (the two
+    // cell tables through whole-table temporaries, the pool through a staging buffer of kFileChunk bytes)
     std::vector<unsigned char> stage(kFileChunk);
-    const void* src[3] = {c->d_coarse, c->d_meta, c->d_pool};
+    const int cd[3] = {c->view.cx, c->view.cy, c->view.cz};
+    struct Temps {
+        uint32_t *coarse = nullptr, *pool = nullptr;
+        uint2* meta = nullptr;
+        ~Temps() { (void)hipFree(coarse); (void)hipFree(meta); (void)hipFree(pool); }
+    } T;
+    VX_HIP(hipMalloc((void**)&T.coarse, h.coarse_bytes));
+    VX_HIP(hipMalloc((void**)&T.meta, h.meta_bytes));
+    VX_HIP(hipMalloc((void**)&T.pool, std::max<uint64_t>(4, std::min<uint64_t>(kFileChunk, h.pool_bytes))));
+    VX_HIP(vxrt::layout_bits(c->d_coarse, T.coarse, cd, false));
+    VX_HIP(vxrt::layout_meta(c->d_meta, T.meta, cd, false));
+    const void* src[3] = {T.coarse, T.meta, nullptr};
     const uint64_t bytes[3] = {h.coarse_bytes, h.meta_bytes, h.pool_bytes};
+    const uint64_t brick_bytes = (uint64_t)c->view.brick_words * 4;
     for (int t = 0; t < 3; ++t) {
         StreamSum cs;
         for (uint64_t off = 0; off < bytes[t]; off += kFileChunk) {
             const size_t n = (size_t)std::min<uint64_t>(kFileChunk, bytes[t] - off);
-            VX_HIP(hipMemcpy(stage.data(), static_cast<const unsigned char*>(src[t]) + off, n, hipMemcpyDeviceToHost));
+            if (t == 2) {  // kFileChunk is a whole number of bricks
+                VX_HIP(vxrt::layout_bricks(c->d_pool + off / 4, T.pool, n / brick_bytes, c->view.f, false));
+                VX_HIP(hipMemcpy(stage.data(), T.pool, n, hipMemcpyDeviceToHost));
+            } else {
+                VX_HIP(hipMemcpy(stage.data(), static_cast<const unsigned char*>(src[t]) + off, n, hipMemcpyDeviceToHost));
+            }
             cs.add(stage.data(), n);
             if (fwrite(stage.data(), 1, n, fc.f) != n)
                 return fail(VXRT_ERR_INVALID, std::string(path) + ": write failed (disk full?)");
@@ -1014,12 +1090,29 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
     // owns a brick inside the pool, every empty one owns none
     std::vector<unsigned char> stage(kFileChunk);
     std::vector<uint32_t> coarse(h.coarse_bytes / 4);
-    void* dst[3] = {c->d_coarse, c->d_meta, c->d_pool};
-    const uint64_t bytes[3] = {h.coarse_bytes, h.meta_bytes, h.pool_bytes};
+    // the file's tables are in the reference's tiled order: the two cell tables land in device temporaries and are
+    // re-ordered into the HBM order when their stream is complete, the pool piece by piece in place
+    struct Temps {
+        uint32_t* coarse = nullptr;
+        uint2* meta = nullptr;
+        ~Temps() { (void)hipFree(coarse); (void)hipFree(meta); }
+    } T;
     auto bad = [&](const std::string& why) {
         vxrt::free_world(c);
         return fail(VXRT_ERR_INVALID, std::string(path) + ": " + why);
     };
+    auto bad_hip = [&](hipError_t e) {
+        vxrt::free_world(c);
+        return fail(VXRT_ERR_HIP, std::string("world load: ") + hipGetErrorString(e));
+    };
+    hipError_t e = hipMalloc((void**)&T.coarse, h.coarse_bytes);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&T.meta, h.meta_bytes);
+    if (e != hipSuccess)
+        return bad_hip(e);
+    void* dst[3] = {T.coarse, T.meta, c->d_pool};
+    const uint64_t bytes[3] = {h.coarse_bytes, h.meta_bytes, h.pool_bytes};
+    const uint64_t brick_bytes = (uint64_t)h.factor * h.factor * h.factor / 8;
     for (int t = 0; t < 3; ++t) {
         StreamSum cs;
         for (uint64_t off = 0; off < bytes[t]; off += kFileChunk) {
@@ -1045,15 +1138,24 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
                         }
                 }
             }
-            hipError_t e = hipMemcpy(static_cast<unsigned char*>(dst[t]) + off, stage.data(), n, hipMemcpyHostToDevice);
-            if (e != hipSuccess) {
-                vxrt::free_world(c);
-                return fail(VXRT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
-            }
+            e = hipMemcpy(static_cast<unsigned char*>(dst[t]) + off, stage.data(), n, hipMemcpyHostToDevice);
+            if (e == hipSuccess && t == 2)  // kFileChunk is a whole number of bricks
+                e = vxrt::layout_bricks(c->d_pool + off / 4, c->d_pool + off / 4, n / brick_bytes, h.factor, true);
+            if (e != hipSuccess)
+                return bad_hip(e);
         }
         if (cs.a != h.sum[t] || cs.b != h.sum2[t])
             return bad("checksum mismatch (corrupt file)");
+        if (t == 0)
+            e = vxrt::layout_bits(T.coarse, c->d_coarse, cd, true);
+        if (t == 1)
+            e = vxrt::layout_meta(T.meta, c->d_meta, cd, true);
+        if (e != hipSuccess)
+            return bad_hip(e);
     }
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess)
+        return bad_hip(e);
     c->nslots = h.nslots;
     vxrt::fill_view(c, h.factor, cd);
     c->has_world = true;
@@ -1076,6 +1178,7 @@ struct StreamState {
     };
     std::vector<Chunk> chunks;
     std::map<uint64_t, uint64_t> free_ranges;   // device pool: start -> length, in bricks
+    uint2* d_chunk_meta = nullptr;              // device staging for one chunk's 512 cell records
     uint64_t capacity = 0, bricks_resident = 0, chunks_resident = 0, chunks_occupied = 0;
 
     bool alloc(uint64_t n, uint64_t& start)
@@ -1117,6 +1220,7 @@ void stream_drop(vxrt_ctx* c)
         return;
     if (c->stream->f)
         fclose(c->stream->f);
+    (void)hipFree(c->stream->d_chunk_meta);
     delete c->stream;
     c->stream = nullptr;
 }
@@ -1204,6 +1308,8 @@ int vxrt_stream_open(vxrt_ctx* c, const char* path, uint64_t pool_capacity_brick
     hipError_t e = hipMemset(c->d_coarse, 0, h.coarse_bytes);
     if (e == hipSuccess)
         e = hipMemcpy(c->d_meta, empty.data(), h.meta_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&S->d_chunk_meta, 512 * sizeof(uint2));
     if (e != hipSuccess) {
         vxrt::free_world(c);
         return bad(VXRT_ERR_HIP, std::string("stream tables: ") + hipGetErrorString(e));
@@ -1253,13 +1359,14 @@ int vxrt_stream_focus(vxrt_ctx* c, const float focus[3], float radius, vxrt_stre
             const uint2 m = S->meta[(uint64_t)ch * 512 + i];
             meta[i] = (resident && m.x != VXRT_EMPTY_SLOT) ? make_uint2((uint32_t)(C.base + k++), m.y) : make_uint2(VXRT_EMPTY_SLOT, 0u);
         }
-        hipError_t e = hipMemcpy(c->d_meta + (uint64_t)ch * 512, meta.data(), 512 * sizeof(uint2), hipMemcpyHostToDevice);
+        // the chunk's 512 records (file order: the reference's tiled order, one chunk = one tile) go to their places in
+        // the HBM tables -- 64 rows of 8 cells -- with their coarse bits
+        hipError_t e = hipMemcpy(S->d_chunk_meta, meta.data(), 512 * sizeof(uint2), hipMemcpyHostToDevice);
         if (e != hipSuccess)
             return e;
-        uint32_t bits[16];  // one 8x8x8 tile of coarse cells = 512 bits = one 64-byte line
-        for (int w = 0; w < 16; ++w)
-            bits[w] = resident ? S->coarse[(uint64_t)ch * 16 + w] : 0u;
-        return hipMemcpy(c->d_coarse + (uint64_t)ch * 16, bits, sizeof(bits), hipMemcpyHostToDevice);
+        const int tw = S->h.cdims[0] / 8, th = S->h.cdims[1] / 8;
+        return vxrt::chunk_tables(c->d_meta, c->d_coarse, S->d_chunk_meta, (int)(ch % (uint32_t)tw), (int)((ch / (uint32_t)tw) % (uint32_t)th),
+                                  (int)(ch / ((uint32_t)tw * (uint32_t)th)), S->h.cdims[0], S->h.cdims[1]);
     };
     for (size_t k = 0; k < order.size() && order[k].first <= r2; ++k) {
         const uint32_t ch = order[k].second;
@@ -1296,6 +1403,10 @@ int vxrt_stream_focus(vxrt_ctx* c, const float focus[3], float radius, vxrt_stre
         }
         bytes += nbytes;
         hipError_t e = hipMemcpy(reinterpret_cast<unsigned char*>(c->d_pool) + start * S->brick_bytes, stage.data(), nbytes, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {  // the file's bricks are in the reference's tiled bit order: into the HBM order, in place
+            uint32_t* at = c->d_pool + start * (S->brick_bytes / 4);
+            e = vxrt::layout_bricks(at, at, C.nbricks, S->h.factor, true);
+        }
         if (e != hipSuccess) {
             S->release(start, C.nbricks);
             return fail(VXRT_ERR_HIP, std::string("hipMemcpy: ") + hipGetErrorString(e));
@@ -1306,6 +1417,7 @@ int vxrt_stream_focus(vxrt_ctx* c, const float focus[3], float radius, vxrt_stre
         S->chunks_resident += 1;
         loaded += 1;
     }
+    VX_HIP(hipDeviceSynchronize());  // the table updates and re-ordered bricks are in place before any launch reads them
     if (out) {
         out->chunks_total = S->nchunks;
         out->chunks_occupied = S->chunks_occupied;

@@ -207,8 +207,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_OCC) void k_render_pool(RenderArgs
             T.dm1_x = W.cx - 1;
             T.dm1_y = W.cy - 1;
             T.dm1_z = W.cz - 1;
-            T.tw = W.ctw;
-            T.twh = W.ctwh;
+            T.row = W.c_row;
+            T.slice = W.c_slice;
             my_tag = m >> 7;
             T.st = ST_WALK;
         }

@@ -92,13 +92,13 @@ struct WaveTracer {
     uint32_t st, fine, wf, w_code, skip;
     f3 ws, point;
     int cell_x, cell_y, cell_z, lim_x, lim_y, lim_z;
-    int dm1_x, dm1_y, dm1_z, tw, twh;  // per-walk level constants kept in registers: dimension-1, tiles per row/slice
+    int dm1_x, dm1_y, dm1_z, row, slice;  // per-walk level constants kept in registers: dimension-1, cells per row / slice
     int up_x, up_y, up_z;              // per-ray: 1 where the direction component is positive (:195-197)
     float tn_x, tn_y, tn_z;
     int steps;  // stepsTaken; also the reference's loop index: an iteration continues exactly when a step is counted
     // coarse results kept across the brick walk (cold)
     int chx, chy, chz, nc_axis;
-    uint32_t c_code, slot, c_ci;  // c_ci: tiled index of the coarse HitCell (previous_cell compares it, :402-407)
+    uint32_t c_code, slot, c_ci;  // c_ci: cell index of the coarse HitCell (previous_cell compares it, :402-407)
     const uint32_t* bits;
     RayCounters cnt;
     uint32_t* cold;  // LDS_COLD: &block[lane]; field F of this lane is cold[F * 64]
@@ -129,8 +129,8 @@ struct WaveTracer {
         cell_x = cell_y = cell_z = 0;
         lim_x = lim_y = lim_z = 0;
         dm1_x = dm1_y = dm1_z = 0;
-        tw = W.ctw;
-        twh = W.ctwh;
+        row = W.c_row;
+        slice = W.c_slice;
         up_x = 1;
         up_y = up_z = 0;
         tn_x = tn_y = tn_z = 0.0f;
@@ -185,8 +185,8 @@ struct WaveTracer {
         dm1_x = dmx - 1;
         dm1_y = dmy - 1;
         dm1_z = dmz - 1;
-        tw = to_fine ? W.ftw : W.ctw;
-        twh = to_fine ? W.ftwh : W.ctwh;
+        row = to_fine ? W.f_row : W.c_row;
+        slice = to_fine ? W.f_slice : W.c_slice;
     }
 
     // Raytrace's prologue (:359-384): per-ray constants, world entry, first coarse walk
@@ -222,7 +222,7 @@ struct WaveTracer {
         cput(CF_START_Z, start.z, s0.z);
         if (!LDS_COLD)
             entry_code = ec;
-        cput(CF_LAST_CI, last_ci, 0xFFFFFFFFu);  // previous_cell as its tiled index (unique per cell); none yet
+        cput(CF_LAST_CI, last_ci, 0xFFFFFFFFu);  // previous_cell as its cell index (unique per cell); none yet
         cput(CF_TOTAL, total, 0);
         if (!LDS_COLD) {
             ray_hit = false;
@@ -321,7 +321,7 @@ struct WaveTracer {
     __device__ __forceinline__ void phase_box(const WorldView& W)
     {
         const int qx = min(cell_x, W.cx - 1), qy = min(cell_y, W.cy - 1), qz = min(cell_z, W.cz - 1);
-        const uint32_t idx = tiled_index(qx, qy, qz, W.ctw, W.ctwh);
+        const uint32_t idx = cell_index(qx, qy, qz, W.c_row, W.c_slice);
         const uint2 meta = W.cell_meta[idx];
         const uint32_t e = meta.y;
         f3 bmin = mk3(((float)(e & 31u) + 0) * W.inv_f + (float)qx, ((float)((e >> 5) & 31u) + 0) * W.inv_f + (float)qy,
@@ -379,7 +379,7 @@ struct WaveTracer {
         // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); an out-of-range
         // lane reads word 0 instead, so the unconditional load below always has a valid address
         const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
-        const uint32_t idx_raw = tiled_index(qx, qy, qz, tw, twh);
+        const uint32_t idx_raw = cell_index(qx, qy, qz, row, slice);
         const uint32_t idx = lane_test(in) ? idx_raw : 0u;
         // MASKED_LOAD: only walking lanes load.  In the render kernels the load is unconditional (parked lanes re-read
         // their last word from L1/L2; the exec-mask branch around the load costs 3.6 % of the frame rate); for a batch
@@ -452,7 +452,7 @@ struct WaveTracer {
         const lanemask_t w1 = lane_mask(st == ST_WALK);
         const lanemask_t in1 = lane_mask((uint32_t)cell_x < (uint32_t)lim_x) & lane_mask((uint32_t)cell_y < (uint32_t)lim_y) &
                                lane_mask((uint32_t)cell_z < (uint32_t)lim_z);
-        const uint32_t idx1_raw = tiled_index(min(cell_x, dm1_x), min(cell_y, dm1_y), min(cell_z, dm1_z), tw, twh);
+        const uint32_t idx1_raw = cell_index(min(cell_x, dm1_x), min(cell_y, dm1_y), min(cell_z, dm1_z), row, slice);
         const uint32_t idx1 = lane_test(in1) ? idx1_raw : 0u;
         uint32_t word1 = 0u;
 #ifdef VXRT_SLICE64  // experiment (north_star's wide bitmask loads): fetch the 64-bit z-slice of the tile (8 x 8 cells in x, y)
@@ -480,7 +480,7 @@ struct WaveTracer {
         const int nx = cell_x + (on0 ? 2 * up_x - 1 : 0), ny = cell_y + (on1 ? 2 * up_y - 1 : 0), nz = cell_z + (on2 ? 2 * up_z - 1 : 0);
         const lanemask_t in2 = lane_mask((uint32_t)nx < (uint32_t)lim_x) & lane_mask((uint32_t)ny < (uint32_t)lim_y) &
                                lane_mask((uint32_t)nz < (uint32_t)lim_z);
-        const uint32_t idx2_raw = tiled_index(min(nx, dm1_x), min(ny, dm1_y), min(nz, dm1_z), tw, twh);
+        const uint32_t idx2_raw = cell_index(min(nx, dm1_x), min(ny, dm1_y), min(nz, dm1_z), row, slice);
         const uint32_t idx2 = lane_test(in2) ? idx2_raw : 0u;
         uint32_t word2 = 0u;
 #ifdef VXRT_SLICE64

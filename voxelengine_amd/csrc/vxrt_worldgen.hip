@@ -153,8 +153,9 @@ __device__ __forceinline__ bool g_solid(int x, int y, int z, int Y)
 // per (x,z); the generic path below simply evaluates every voxel, which is what PERLIN_REF (a true 3-D
 // field) requires anyway.
 
-// one workgroup per brick cell (in tiled order); writes the brick's bit image to scratch[cell],
-// its packed extents to ext[cell] and any[cell]
+// one workgroup per brick cell, cells enumerated in the reference's tiled order (slot numbers follow that order: it is
+// the order of the brickmap file, where the bricks of an 8x8x8-cell chunk are one contiguous run); writes the brick's
+// bit image -- in HBM order, x-fastest linear -- to scratch[cell], its packed extents to ext[cell] and any[cell]
 template <int GEN>
 __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scratch, uint32_t* __restrict__ ext,
                                                      uint8_t* __restrict__ any, int ctw, int cth, int f, int Y,
@@ -164,11 +165,8 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
     const uint32_t cell = blockIdx.x + blockIdx.y * gridDim.x;  // 2-D grid: more cells than one grid axis holds
     if (cell >= ncells)
         return;
-    // inverse of the tiled index for the brick cell (GetPositionFromSampleIndex, VolumeRaytracer.cuh:138-171)
-    const uint32_t tile = cell >> 9, in = cell & 511u;
-    const int bx = (int)((tile % (uint32_t)ctw) * 8u + (in & 7u));
-    const int by = (int)(((tile / (uint32_t)ctw) % (uint32_t)cth) * 8u + ((in >> 3) & 7u));
-    const int bz = (int)((tile / ((uint32_t)ctw * (uint32_t)cth)) * 8u + (in >> 6));
+    int bx, by, bz;  // inverse of the tiled index for the brick cell (GetPositionFromSampleIndex, VolumeRaytracer.cuh:138-171)
+    ref_tiled_cell(cell, ctw, cth, bx, by, bz);
     if (threadIdx.x < 3)
         red[threadIdx.x] = 0x7FFFFFFF;
     else if (threadIdx.x < 6)
@@ -177,19 +175,16 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
         red[6] = 0;
     __syncthreads();
 
-    // One voxel per lane: a wave's 64 consecutive bits are one z-slice (8x8) of one 8^3 tile of the brick, and the
-    // ballot mask IS that uint64 of the bit image.  Every lane is busy for every brick edge (f = 8: 512 voxels on
-    // 256 threads; the earlier one-word-per-lane form left 240 of them idle there).
-    const int ftw = f >> 3;
+    // One voxel per lane: a wave's 64 consecutive bits are 64 / f whole x-rows of the brick, and the ballot mask IS
+    // that uint64 of the bit image.  Every lane is busy for every brick edge (f = 8: 512 voxels on 256 threads; the
+    // earlier one-word-per-lane form left 240 of them idle there).
+    const int fshift = f == 32 ? 5 : (f == 16 ? 4 : 3);
     const uint32_t words = (uint32_t)(f * f * f) >> 5, nbits = words << 5;
     int mnx = 0x7FFFFFFF, mny = 0x7FFFFFFF, mnz = 0x7FFFFFFF, mxx = -1, mxy = -1, mxz = -1;
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(scratch + (size_t)cell * words);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t o = threadIdx.x; o < nbits; o += blockDim.x) {  // nbits is a multiple of 512: whole waves iterate
-        const uint32_t bt = o >> 9;  // tile inside the brick
-        const int tx = (int)(bt % (uint32_t)ftw), ty = (int)((bt / (uint32_t)ftw) % (uint32_t)ftw),
-                  tz = (int)(bt / (uint32_t)(ftw * ftw));
-        const int lx = tx * 8 + (int)(o & 7u), ly = ty * 8 + (int)((o >> 3) & 7u), lz = tz * 8 + (int)((o >> 6) & 7u);
+        const int lx = (int)(o & (uint32_t)(f - 1)), ly = (int)((o >> fshift) & (uint32_t)(f - 1)), lz = (int)(o >> (2 * fshift));
         const bool solid = g_solid<GEN>(bx * f + lx, by * f + ly, bz * f + lz, Y);
         const unsigned long long mask = __ballot(solid);
         if (lane == 0)
@@ -215,17 +210,21 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
     }
 }
 
-// pack non-empty bricks into the pool, 16 bytes per lane, and write the cell_meta records
+// pack non-empty bricks into the pool, 16 bytes per lane, and write the cell_meta records (at the cell's HBM index)
 __global__ __launch_bounds__(256) void k_pack_bricks(const uint4* __restrict__ scratch, const uint32_t* __restrict__ slot,
                                                      const uint32_t* __restrict__ ext, uint4* __restrict__ pool,
-                                                     uint2* __restrict__ meta, uint32_t vecs_per_brick, uint32_t ncells)
+                                                     uint2* __restrict__ meta, uint32_t vecs_per_brick, uint32_t ncells,
+                                                     int cx, int cy)
 {
     const uint32_t cell = blockIdx.x + blockIdx.y * gridDim.x;
     if (cell >= ncells)
         return;
     const uint32_t s = slot[cell];
-    if (threadIdx.x == 0)
-        meta[cell] = make_uint2(s, ext[cell]);
+    if (threadIdx.x == 0) {
+        int bx, by, bz;
+        ref_tiled_cell(cell, cx / 8, cy / 8, bx, by, bz);
+        meta[(size_t)bx + (size_t)cx * ((size_t)by + (size_t)cy * (size_t)bz)] = make_uint2(s, ext[cell]);
+    }
     if (s == kEmptySlot)
         return;
     const uint4* src = scratch + (size_t)cell * vecs_per_brick;
@@ -234,20 +233,156 @@ __global__ __launch_bounds__(256) void k_pack_bricks(const uint4* __restrict__ s
         dst[i] = src[i];
 }
 
-// coarse bit = brick non-empty (VolumeRaytracer.cuh:504-507), one word per lane
-__global__ void k_coarse_bits(const uint8_t* __restrict__ any, uint32_t* __restrict__ coarse, uint64_t ncells)
+// coarse bit = brick non-empty (VolumeRaytracer.cuh:504-507), one word of the HBM order per lane; any[] is in the
+// builder's tiled cell order
+__global__ void k_coarse_bits(const uint8_t* __restrict__ any, uint32_t* __restrict__ coarse, int cx, int cy, int cz)
 {
-    uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t nwords = (ncells + 31) / 32;
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t ncells = (uint64_t)cx * cy * cz, nwords = (ncells + 31) / 32;
     if (w >= nwords)
         return;
     uint32_t bits = 0;
     for (uint32_t k = 0; k < 32u; ++k) {
-        uint64_t i = w * 32u + k;
-        if (i < ncells && any[i])
+        const uint64_t i = w * 32u + k;
+        if (i >= ncells)
+            break;
+        const int x = (int)(i % (uint64_t)cx), y = (int)((i / (uint64_t)cx) % (uint64_t)cy), z = (int)(i / ((uint64_t)cx * cy));
+        if (any[ref_tiled_index(x, y, z, cx / 8, cy / 8)])
             bits |= 1u << k;
     }
     coarse[w] = bits;
+}
+
+// ---- re-ordering between the reference's tiled bit order (C ABI, brickmap file) and the HBM order ---------------------
+// TO_HBM: src is tiled, dst linear; else the inverse.  One destination word per lane, 32 gathered bits.
+template <bool TO_HBM>
+__global__ void k_layout_bits(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int dx, int dy, int dz)
+{
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n = (uint64_t)dx * dy * dz;
+    if (w * 32u >= n)
+        return;
+    uint32_t bits = 0;
+    for (uint32_t k = 0; k < 32u; ++k) {
+        const uint64_t i = w * 32u + k;
+        if (i >= n)
+            break;
+        uint64_t from;
+        if (TO_HBM) {
+            const int x = (int)(i % (uint64_t)dx), y = (int)((i / (uint64_t)dx) % (uint64_t)dy), z = (int)(i / ((uint64_t)dx * dy));
+            from = ref_tiled_index(x, y, z, dx / 8, dy / 8);
+        } else {
+            int x, y, z;
+            ref_tiled_cell((uint32_t)i, dx / 8, dy / 8, x, y, z);
+            from = (uint64_t)x + (uint64_t)dx * ((uint64_t)y + (uint64_t)dy * (uint64_t)z);
+        }
+        bits |= ((src[from >> 5] >> (from & 31u)) & 1u) << k;
+    }
+    dst[w] = bits;
+}
+
+template <bool TO_HBM>
+__global__ void k_layout_meta(const uint2* __restrict__ src, uint2* __restrict__ dst, int dx, int dy, int dz)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)dx * dy * dz)
+        return;
+    int x, y, z;
+    if (TO_HBM) {
+        x = (int)(i % (uint64_t)dx);
+        y = (int)((i / (uint64_t)dx) % (uint64_t)dy);
+        z = (int)(i / ((uint64_t)dx * dy));
+        dst[i] = src[ref_tiled_index(x, y, z, dx / 8, dy / 8)];
+    } else {
+        ref_tiled_cell((uint32_t)i, dx / 8, dy / 8, x, y, z);
+        dst[i] = src[(uint64_t)x + (uint64_t)dx * ((uint64_t)y + (uint64_t)dy * (uint64_t)z)];
+    }
+}
+
+// one workgroup per brick, staged through LDS: src and dst may be the same brick (in place)
+template <bool TO_HBM>
+__global__ __launch_bounds__(256) void k_layout_bricks(const uint32_t* src, uint32_t* dst, int f)
+{
+    __shared__ uint32_t old_words[1024];  // f <= 32
+    const uint32_t words = (uint32_t)(f * f * f) / 32u;
+    const uint32_t* in = src + (size_t)blockIdx.x * words;
+    uint32_t* out = dst + (size_t)blockIdx.x * words;
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x)
+        old_words[i] = in[i];
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < words; w += blockDim.x) {
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < 32u; ++k) {
+            const uint32_t i = w * 32u + k;
+            uint32_t from;
+            if (TO_HBM) {
+                const int x = (int)(i % (uint32_t)f), y = (int)((i / (uint32_t)f) % (uint32_t)f), z = (int)(i / (uint32_t)(f * f));
+                from = ref_tiled_index(x, y, z, f / 8, f / 8);
+            } else {
+                int x, y, z;
+                ref_tiled_cell(i, f / 8, f / 8, x, y, z);
+                from = (uint32_t)(x + f * (y + f * z));
+            }
+            bits |= ((old_words[from >> 5] >> (from & 31u)) & 1u) << k;
+        }
+        out[w] = bits;
+    }
+}
+
+// chunk streaming: the cell records and coarse bits of ONE 8x8x8-cell chunk (chunk_meta: its 512 records in the file's
+// tiled order, slots already translated) go to their places in the HBM tables; 8 cells of a row share a coarse word
+__global__ __launch_bounds__(512) void k_chunk_tables(uint2* __restrict__ meta, uint32_t* __restrict__ coarse,
+                                                      const uint2* __restrict__ chunk_meta, int tx, int ty, int tz, int cx, int cy)
+{
+    const uint32_t i = threadIdx.x;
+    const int x = tx * 8 + (int)(i & 7u), y = ty * 8 + (int)((i >> 3) & 7u), z = tz * 8 + (int)(i >> 6);
+    const uint64_t at = (uint64_t)x + (uint64_t)cx * ((uint64_t)y + (uint64_t)cy * (uint64_t)z);
+    const uint2 m = chunk_meta[i];
+    meta[at] = m;
+    if (m.x != kEmptySlot)
+        atomicOr(&coarse[at >> 5], 1u << (at & 31u));
+    else
+        atomicAnd(&coarse[at >> 5], ~(1u << (at & 31u)));
+}
+
+// host entry points of the above (vxrt_api.hip)
+hipError_t layout_bits(const uint32_t* src, uint32_t* dst, const int cd[3], bool to_hbm)
+{
+    const uint64_t nwords = ((uint64_t)cd[0] * cd[1] * cd[2] + 31) / 32;
+    const dim3 g((unsigned)((nwords + 255) / 256)), b(256);
+    if (to_hbm)
+        hipLaunchKernelGGL(k_layout_bits<true>, g, b, 0, 0, src, dst, cd[0], cd[1], cd[2]);
+    else
+        hipLaunchKernelGGL(k_layout_bits<false>, g, b, 0, 0, src, dst, cd[0], cd[1], cd[2]);
+    return hipGetLastError();
+}
+hipError_t layout_meta(const uint2* src, uint2* dst, const int cd[3], bool to_hbm)
+{
+    const uint64_t n = (uint64_t)cd[0] * cd[1] * cd[2];
+    const dim3 g((unsigned)((n + 255) / 256)), b(256);
+    if (to_hbm)
+        hipLaunchKernelGGL(k_layout_meta<true>, g, b, 0, 0, src, dst, cd[0], cd[1], cd[2]);
+    else
+        hipLaunchKernelGGL(k_layout_meta<false>, g, b, 0, 0, src, dst, cd[0], cd[1], cd[2]);
+    return hipGetLastError();
+}
+hipError_t layout_bricks(const uint32_t* src, uint32_t* dst, uint64_t nbricks, int f, bool to_hbm)
+{
+    const uint32_t words = (uint32_t)(f * f * f) / 32u;
+    for (uint64_t done = 0; done < nbricks;) {  // a grid axis holds 2^31 - 1 workgroups
+        const uint64_t n = nbricks - done < (1ull << 30) ? nbricks - done : (1ull << 30);
+        if (to_hbm)
+            hipLaunchKernelGGL(k_layout_bricks<true>, dim3((unsigned)n), dim3(256), 0, 0, src + done * words, dst + done * words, f);
+        else
+            hipLaunchKernelGGL(k_layout_bricks<false>, dim3((unsigned)n), dim3(256), 0, 0, src + done * words, dst + done * words, f);
+        done += n;
+    }
+    return hipGetLastError();
+}
+hipError_t chunk_tables(uint2* meta, uint32_t* coarse, const uint2* d_chunk_meta, int tx, int ty, int tz, int cx, int cy)
+{
+    hipLaunchKernelGGL(k_chunk_tables, dim3(1), dim3(512), 0, 0, meta, coarse, d_chunk_meta, tx, ty, tz, cx, cy);
+    return hipGetLastError();
 }
 
 }  // namespace vxrt
@@ -306,7 +441,7 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
     WG_HIP(hipGetLastError());
     WG_HIP(hipDeviceSynchronize());
 
-    // slot numbers in coarse tiled-index order (host scan of one byte per cell)
+    // slot numbers in the reference's tiled cell order (host scan of one byte per cell)
     std::vector<uint8_t> any(ncells);
     WG_HIP(hipMemcpy(any.data(), d_any, ncells, hipMemcpyDeviceToHost));
     std::vector<uint32_t> slot(ncells);
@@ -326,10 +461,10 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
     }
     adopted = true;
     hipLaunchKernelGGL(k_pack_bricks, grid, block, 0, 0, (const uint4*)d_scratch, d_slot, d_ext, (uint4*)d_pool, d_meta,
-                       (uint32_t)(bw / 4), (uint32_t)ncells);
+                       (uint32_t)(bw / 4), (uint32_t)ncells, cd[0], cd[1]);
     WG_HIP(hipGetLastError());
     uint64_t nwords = (ncells + 31) / 32;
-    hipLaunchKernelGGL(k_coarse_bits, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, 0, d_any, d_coarse, ncells);
+    hipLaunchKernelGGL(k_coarse_bits, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, 0, d_any, d_coarse, cd[0], cd[1], cd[2]);
     WG_HIP(hipGetLastError());
     WG_HIP(hipDeviceSynchronize());
     done = true;
