@@ -60,7 +60,9 @@ int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 /* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,
  * ::UploadVoxelBufferDatas, ::UploadVoxelBufferDataBounds and ::SetFactor
  * (VoxelRT/VolumeRaytracer.cu:527-572, VolumeRaytracer.cuh:349).  The three
- * reference tables are handed over as flat host arrays and copied into HBM:
+ * reference tables are handed over as flat host arrays in the reference's own order and copied into HBM (where the
+ * library keeps them in an order of its own, x-fastest linear: vxrt_download_world and the brickmap file give the
+ * reference's order back):
  *   coarse_bits : one bit per brick cell, tiled-linear order of GetSampleIndex
  *                 (VolumeRaytracer.cuh:107-131), (ncells+31)/32 words
  *   brick_slot  : per cell, index of the brick in `pool` or VXRT_EMPTY_SLOT
@@ -122,8 +124,8 @@ int vxrt_world_file_info(const char *path, vxrt_world_info *out);
  * (README.md:15,20).  A world whose bricks need not all be resident: the coarse tables of the whole world stay in HBM
  * (128 KiB + 8 MiB for 8192x512x8192), the brick pool is a cache of `pool_capacity_bricks` bricks, and brick data is
  * read from a brickmap file (vxrt_save_world) for the CHUNKS near a focus point only.  A chunk is one 8x8x8 tile of
- * coarse cells -- 512 consecutive records of the tiled-linear tables and one contiguous run of bricks in the file, so a
- * chunk arrives with one read and three copies.  A chunk that is not resident reads as EMPTY space: the kernels do not
+ * coarse cells -- 512 consecutive records of the file's tiled-linear tables and one contiguous run of bricks, so a
+ * chunk arrives with one read, two copies and two small re-ordering launches.  A chunk that is not resident reads as EMPTY space: the kernels do not
  * change, and every frame equals the frame of the world with exactly the resident chunks' bricks (tests hold the HIP
  * frames equal to the oracle on that truncated world).
  *   vxrt_stream_open: replaces the context's world by the (so far empty) streamed world of `path`.

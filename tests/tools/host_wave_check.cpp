@@ -18,13 +18,13 @@ int main(int argc, char** argv)
     for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
         if (rand() / (double)RAND_MAX < dens) { uint64_t i = vxo_sample_index64(x, y, z, S, S); dense[i >> 5] |= 1u << (i & 31); }
     vxo_world* w = vxo_build_brickmap(dense.data(), S, S, S, f);
-    // the oracle's tables are in the reference's tiled order; the tracer reads the HBM order (x-fastest linear, both
+    // the oracle's tables are in the reference's tiled order; the tracer reads the HBM order (linear x, z, y on both
     // levels): re-order on the host what the library re-orders on the device (vxrt_worldgen.hip)
     const int cx = w->cdims[0], cy = w->cdims[1], cz = w->cdims[2];
     std::vector<uint2> meta(w->ncells);
     std::vector<uint32_t> coarse((w->ncells + 31) / 32, 0u);
     for (int z = 0; z < cz; ++z) for (int y = 0; y < cy; ++y) for (int x = 0; x < cx; ++x) {
-        const uint64_t t = ref_tiled_index(x, y, z, cx / 8, cy / 8), i = (uint64_t)x + (uint64_t)cx * (y + (uint64_t)cy * z);
+        const uint64_t t = ref_tiled_index(x, y, z, cx / 8, cy / 8), i = hbm_index(x, y, z, cx, cz);
         uint32_t p = 0;
         if (w->brick_slot[t] != VXO_EMPTY_SLOT) for (int k = 0; k < 6; ++k) p |= (uint32_t)(int)w->bounds[t * 6 + k] << (5 * k);
         meta[i] = make_uint2(w->brick_slot[t], p);
@@ -34,12 +34,12 @@ int main(int argc, char** argv)
     std::vector<uint32_t> pool((size_t)w->nslots * bw, 0u);
     for (uint64_t s = 0; s < w->nslots; ++s)
         for (int z = 0; z < f; ++z) for (int y = 0; y < f; ++y) for (int x = 0; x < f; ++x) {
-            const uint32_t t = ref_tiled_index(x, y, z, f / 8, f / 8), i = (uint32_t)(x + f * (y + f * z));
+            const uint32_t t = ref_tiled_index(x, y, z, f / 8, f / 8), i = (uint32_t)hbm_index(x, y, z, f, f);
             if ((w->pool[s * bw + (t >> 5)] >> (t & 31)) & 1u) pool[s * bw + (i >> 5)] |= 1u << (i & 31);
         }
     WorldView W{};
     W.coarse_bits = coarse.data(); W.cell_meta = meta.data(); W.pool = pool.data();
-    W.cx = cx; W.cy = cy; W.cz = cz; W.c_row = cx; W.c_slice = cx * cy;
+    W.cx = cx; W.cy = cy; W.cz = cz; W.c_row = cx; W.c_slice = cx * cz;
     W.f = f; W.f_row = f; W.f_slice = f * f; W.brick_words = bw; W.ff = (float)f; W.inv_f = 1.0f / f;
     W.wmax_x = (float)((double)W.cx - 1e-6); W.wmax_y = (float)((double)W.cy - 1e-6); W.wmax_z = (float)((double)W.cz - 1e-6);
     W.X = S; W.Y = S;

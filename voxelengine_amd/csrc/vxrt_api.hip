@@ -28,7 +28,7 @@ int build_world_on_device(struct ::vxrt_ctx* ctx, int generator, int X, int Y, i
 hipError_t layout_bits(const uint32_t* src, uint32_t* dst, const int cd[3], bool to_hbm);
 hipError_t layout_meta(const uint2* src, uint2* dst, const int cd[3], bool to_hbm);
 hipError_t layout_bricks(const uint32_t* src, uint32_t* dst, uint64_t nbricks, int f, bool to_hbm);  // src == dst: in place
-hipError_t chunk_tables(uint2* meta, uint32_t* coarse, const uint2* d_chunk_meta, int tx, int ty, int tz, int cx, int cy);
+hipError_t chunk_tables(uint2* meta, uint32_t* coarse, const uint2* d_chunk_meta, int tx, int ty, int tz, int cx, int cz);
 }  // namespace vxrt
 
 static thread_local std::string g_last_error = "";
@@ -110,9 +110,9 @@ int check_shape(int factor, const int cd[3])
     for (int a = 0; a < 3; ++a)
         if (cd[a] <= 0 || cd[a] % 8 != 0 || cd[a] > 65535)
             return fail(VXRT_ERR_INVALID, "coarse dimensions must be positive multiples of 8 (the tables' tiled order)");
-    // cell_index(): 24-bit multiply-adds on the strides cx and cx * cy, 32-bit cell indices
-    if ((uint64_t)cd[0] * (uint64_t)cd[1] >= (1ull << 24) || (uint64_t)cd[0] * cd[1] * cd[2] >= (1ull << 32))
-        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit cell indices (cx * cy must stay below 2^24)");
+    // cell_index(): 24-bit multiply-adds on the strides cx and cx * cz, 32-bit cell indices
+    if ((uint64_t)cd[0] * (uint64_t)cd[2] >= (1ull << 24) || (uint64_t)cd[0] * cd[1] * cd[2] >= (1ull << 32))
+        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit cell indices (cx * cz must stay below 2^24)");
     return VXRT_OK;
 }
 
@@ -126,7 +126,7 @@ void fill_view(vxrt_ctx* c, int factor, const int cd[3])
     v.cy = cd[1];
     v.cz = cd[2];
     v.c_row = cd[0];
-    v.c_slice = cd[0] * cd[1];
+    v.c_slice = cd[0] * cd[2];
     v.f = factor;
     v.f_row = factor;
     v.f_slice = factor * factor;
@@ -1366,7 +1366,7 @@ int vxrt_stream_focus(vxrt_ctx* c, const float focus[3], float radius, vxrt_stre
             return e;
         const int tw = S->h.cdims[0] / 8, th = S->h.cdims[1] / 8;
         return vxrt::chunk_tables(c->d_meta, c->d_coarse, S->d_chunk_meta, (int)(ch % (uint32_t)tw), (int)((ch / (uint32_t)tw) % (uint32_t)th),
-                                  (int)(ch / ((uint32_t)tw * (uint32_t)th)), S->h.cdims[0], S->h.cdims[1]);
+                                  (int)(ch / ((uint32_t)tw * (uint32_t)th)), S->h.cdims[0], S->h.cdims[2]);
     };
     for (size_t k = 0; k < order.size() && order[k].first <= r2; ++k) {
         const uint32_t ch = order[k].second;

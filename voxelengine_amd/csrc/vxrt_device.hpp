@@ -1,12 +1,12 @@
 // vxrt_device.hpp -- gfx950 device code shared by the kernels of libvxrt.so.
 //
 // HBM layout of a resident world:
-//   coarse_bits : u32 words, one bit per brick cell, x-fastest linear order: bit x + cx * (y + cy * z)
+//   coarse_bits : u32 words, one bit per brick cell, linear order x, z, y: bit x + cx * (z + cz * y)
 //   cell_meta   : one uint2 per brick cell in the same order:
 //                 .x = pool slot of the brick (VXRT_EMPTY_SLOT if empty)
 //                 .y = tight extents, 6 x 5 bits {min x,y,z, max x,y,z}
 //                 (replaces the 24-byte VoxelBuffer3D descriptor + 24-byte Bounds3Df per cell)
-//   pool        : u32 words, nslots bricks of f^3 bits, x-fastest linear inside each brick: bit x + f * (y + f * z)
+//   pool        : u32 words, nslots bricks of f^3 bits, the same linear order inside each brick: bit x + f * (z + f * y)
 // The reference's bit order (GetSampleIndex, VoxelRT/VolumeRaytracer.cuh:107-131: 8x8x8 tiles) is the order of the
 // tables at the C ABI and in the brickmap file; they are re-ordered on the device when a world comes in or goes out
 // (vxrt_worldgen.hip).  In HBM the probe's address is two multiply-adds instead of the twelve bit operations of the
@@ -47,9 +47,9 @@ struct WorldView {
     const uint2* __restrict__ cell_meta;
     const uint32_t* __restrict__ pool;
     int cx, cy, cz;        // coarse cells per axis
-    int c_row, c_slice;    // coarse cells per row (cx), per slice (cx * cy): the strides of cell_index()
+    int c_row, c_slice;    // coarse cells per x-row (cx), per x-z plane (cx * cz): the strides of cell_index()
     int f;                 // brick edge (8, 16, 32)
-    int f_row, f_slice;    // brick voxels per row (f), per slice (f * f)
+    int f_row, f_slice;    // brick voxels per x-row (f), per x-z plane (f * f)
     uint32_t brick_words;  // f^3 / 32
     float ff;              // (float)f
     float inv_f;           // 1/f, exact because f is a power of two: x / f == x * inv_f bit for bit
@@ -86,12 +86,26 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
 }
 #endif
 
+// HBM order: x fastest, then z, then y -- bit x + row * z + slice * y, row = cells along x, slice = cells in an x-z
+// plane.  y last because it is the world's short, vertical axis: rays move mostly in x and z, so consecutive probes of
+// a ray stay in one word (x steps) or one 64-byte line (z steps) more often than with y in the middle.
 __device__ __forceinline__ uint32_t cell_index(int x, int y, int z, int row, int slice)
 {
     // 24-bit multiply-adds (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate): coordinates < 2^16, strides < 2^24
     // (checked when a world is uploaded or built).  Spelled as the instruction: given __umul24 the compiler still
     // selects the 32-bit multiply when it cannot prove the operands' width.
-    return mad24((uint32_t)z, (uint32_t)slice, mad24((uint32_t)y, (uint32_t)row, (uint32_t)x));
+    return mad24((uint32_t)y, (uint32_t)slice, mad24((uint32_t)z, (uint32_t)row, (uint32_t)x));
+}
+// the same order for the cold code (re-ordering kernels, builders, host): index of a cell of a dx x dy x dz grid, and back
+__host__ __device__ inline uint64_t hbm_index(int x, int y, int z, int dx, int dz)
+{
+    return (uint64_t)x + (uint64_t)dx * ((uint64_t)z + (uint64_t)dz * (uint64_t)y);
+}
+__host__ __device__ inline void hbm_cell(uint64_t i, int dx, int dz, int& x, int& y, int& z)
+{
+    x = (int)(i % (uint64_t)dx);
+    z = (int)((i / (uint64_t)dx) % (uint64_t)dz);
+    y = (int)(i / ((uint64_t)dx * (uint64_t)dz));
 }
 
 // The reference's bit order (GetSampleIndex / GetPositionFromSampleIndex, VolumeRaytracer.cuh:107-171): 8x8x8 tiles,

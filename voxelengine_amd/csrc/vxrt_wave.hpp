@@ -455,16 +455,8 @@ struct WaveTracer {
         const uint32_t idx1_raw = cell_index(min(cell_x, dm1_x), min(cell_y, dm1_y), min(cell_z, dm1_z), row, slice);
         const uint32_t idx1 = lane_test(in1) ? idx1_raw : 0u;
         uint32_t word1 = 0u;
-#ifdef VXRT_SLICE64  // experiment (north_star's wide bitmask loads): fetch the 64-bit z-slice of the tile (8 x 8 cells in x, y)
-        // and let the second probe of the pair reuse it while the lane stays inside that slice
-        uint2 slice = make_uint2(0u, 0u);
-        if (!MASKED_LOAD || st == ST_WALK)
-            slice = reinterpret_cast<const uint2*>(bits)[idx1 >> 6];
-        word1 = (idx1 & 32u) ? slice.y : slice.x;
-#else
         if (!MASKED_LOAD || st == ST_WALK)
             word1 = bits[idx1 >> 5];
-#endif
         const lanemask_t is_fine = lane_mask(fine != 0u), skipping = lane_mask(skip != 0u);
         // ---- probe 1: the DDA advance, as far as it does not need the word (:293-322)
         const lanemask_t lt_xy = lane_mask(tn_x < tn_y), lt_xz = lane_mask(tn_x < tn_z), lt_yz = lane_mask(tn_y < tn_z);
@@ -483,17 +475,8 @@ struct WaveTracer {
         const uint32_t idx2_raw = cell_index(min(nx, dm1_x), min(ny, dm1_y), min(nz, dm1_z), row, slice);
         const uint32_t idx2 = lane_test(in2) ? idx2_raw : 0u;
         uint32_t word2 = 0u;
-#ifdef VXRT_SLICE64
-        {
-            const bool same_slice = (idx2 >> 6) == (idx1 >> 6);
-            word2 = (idx2 & 32u) ? slice.y : slice.x;
-            if (!same_slice && (!MASKED_LOAD || st == ST_WALK))  // only the lanes that left the slice load again
-                word2 = bits[idx2 >> 5];
-        }
-#else
         if (!MASKED_LOAD || st == ST_WALK)
             word2 = bits[idx2 >> 5];
-#endif
         // ---- probe 1: decision and commit
         {
             const lanemask_t solid = lane_mask(((word1 >> (idx1 & 31u)) & 1u) != 0u) & ~skipping;

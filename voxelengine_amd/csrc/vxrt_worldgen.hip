@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
         red[6] = 0;
     __syncthreads();
 
-    // One voxel per lane: a wave's 64 consecutive bits are 64 / f whole x-rows of the brick, and the ballot mask IS
+    // One voxel per lane: a wave's 64 consecutive bits are 64 / f whole x-rows of the brick (HBM order: x, then z, then y), and the ballot mask IS
     // that uint64 of the bit image.  Every lane is busy for every brick edge (f = 8: 512 voxels on 256 threads; the
     // earlier one-word-per-lane form left 240 of them idle there).
     const int fshift = f == 32 ? 5 : (f == 16 ? 4 : 3);
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(scratch + (size_t)cell * words);
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t o = threadIdx.x; o < nbits; o += blockDim.x) {  // nbits is a multiple of 512: whole waves iterate
-        const int lx = (int)(o & (uint32_t)(f - 1)), ly = (int)((o >> fshift) & (uint32_t)(f - 1)), lz = (int)(o >> (2 * fshift));
+        const int lx = (int)(o & (uint32_t)(f - 1)), lz = (int)((o >> fshift) & (uint32_t)(f - 1)), ly = (int)(o >> (2 * fshift));  // HBM order: x, z, y
         const bool solid = g_solid<GEN>(bx * f + lx, by * f + ly, bz * f + lz, Y);
         const unsigned long long mask = __ballot(solid);
         if (lane == 0)
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_fill_bricks(uint32_t* __restrict__ scra
 __global__ __launch_bounds__(256) void k_pack_bricks(const uint4* __restrict__ scratch, const uint32_t* __restrict__ slot,
                                                      const uint32_t* __restrict__ ext, uint4* __restrict__ pool,
                                                      uint2* __restrict__ meta, uint32_t vecs_per_brick, uint32_t ncells,
-                                                     int cx, int cy)
+                                                     int cx, int cy, int cz)
 {
     const uint32_t cell = blockIdx.x + blockIdx.y * gridDim.x;
     if (cell >= ncells)
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pack_bricks(const uint4* __restrict__ s
     if (threadIdx.x == 0) {
         int bx, by, bz;
         ref_tiled_cell(cell, cx / 8, cy / 8, bx, by, bz);
-        meta[(size_t)bx + (size_t)cx * ((size_t)by + (size_t)cy * (size_t)bz)] = make_uint2(s, ext[cell]);
+        meta[hbm_index(bx, by, bz, cx, cz)] = make_uint2(s, ext[cell]);
     }
     if (s == kEmptySlot)
         return;
@@ -246,7 +246,8 @@ __global__ void k_coarse_bits(const uint8_t* __restrict__ any, uint32_t* __restr
         const uint64_t i = w * 32u + k;
         if (i >= ncells)
             break;
-        const int x = (int)(i % (uint64_t)cx), y = (int)((i / (uint64_t)cx) % (uint64_t)cy), z = (int)(i / ((uint64_t)cx * cy));
+        int x, y, z;
+        hbm_cell(i, cx, cz, x, y, z);
         if (any[ref_tiled_index(x, y, z, cx / 8, cy / 8)])
             bits |= 1u << k;
     }
@@ -269,12 +270,13 @@ __global__ void k_layout_bits(const uint32_t* __restrict__ src, uint32_t* __rest
             break;
         uint64_t from;
         if (TO_HBM) {
-            const int x = (int)(i % (uint64_t)dx), y = (int)((i / (uint64_t)dx) % (uint64_t)dy), z = (int)(i / ((uint64_t)dx * dy));
+            int x, y, z;
+            hbm_cell(i, dx, dz, x, y, z);
             from = ref_tiled_index(x, y, z, dx / 8, dy / 8);
         } else {
             int x, y, z;
             ref_tiled_cell((uint32_t)i, dx / 8, dy / 8, x, y, z);
-            from = (uint64_t)x + (uint64_t)dx * ((uint64_t)y + (uint64_t)dy * (uint64_t)z);
+            from = hbm_index(x, y, z, dx, dz);
         }
         bits |= ((src[from >> 5] >> (from & 31u)) & 1u) << k;
     }
@@ -289,13 +291,11 @@ __global__ void k_layout_meta(const uint2* __restrict__ src, uint2* __restrict__
         return;
     int x, y, z;
     if (TO_HBM) {
-        x = (int)(i % (uint64_t)dx);
-        y = (int)((i / (uint64_t)dx) % (uint64_t)dy);
-        z = (int)(i / ((uint64_t)dx * dy));
+        hbm_cell(i, dx, dz, x, y, z);
         dst[i] = src[ref_tiled_index(x, y, z, dx / 8, dy / 8)];
     } else {
         ref_tiled_cell((uint32_t)i, dx / 8, dy / 8, x, y, z);
-        dst[i] = src[(uint64_t)x + (uint64_t)dx * ((uint64_t)y + (uint64_t)dy * (uint64_t)z)];
+        dst[i] = src[hbm_index(x, y, z, dx, dz)];
     }
 }
 
@@ -316,12 +316,13 @@ __global__ __launch_bounds__(256) void k_layout_bricks(const uint32_t* src, uint
             const uint32_t i = w * 32u + k;
             uint32_t from;
             if (TO_HBM) {
-                const int x = (int)(i % (uint32_t)f), y = (int)((i / (uint32_t)f) % (uint32_t)f), z = (int)(i / (uint32_t)(f * f));
+                int x, y, z;
+                hbm_cell(i, f, f, x, y, z);
                 from = ref_tiled_index(x, y, z, f / 8, f / 8);
             } else {
                 int x, y, z;
                 ref_tiled_cell(i, f / 8, f / 8, x, y, z);
-                from = (uint32_t)(x + f * (y + f * z));
+                from = (uint32_t)hbm_index(x, y, z, f, f);
             }
             bits |= ((old_words[from >> 5] >> (from & 31u)) & 1u) << k;
         }
@@ -330,13 +331,13 @@ __global__ __launch_bounds__(256) void k_layout_bricks(const uint32_t* src, uint
 }
 
 // chunk streaming: the cell records and coarse bits of ONE 8x8x8-cell chunk (chunk_meta: its 512 records in the file's
-// tiled order, slots already translated) go to their places in the HBM tables; 8 cells of a row share a coarse word
+// tiled order, slots already translated) go to their places in the HBM tables; 8 cells of an x-row share a coarse word
 __global__ __launch_bounds__(512) void k_chunk_tables(uint2* __restrict__ meta, uint32_t* __restrict__ coarse,
-                                                      const uint2* __restrict__ chunk_meta, int tx, int ty, int tz, int cx, int cy)
+                                                      const uint2* __restrict__ chunk_meta, int tx, int ty, int tz, int cx, int cz)
 {
     const uint32_t i = threadIdx.x;
     const int x = tx * 8 + (int)(i & 7u), y = ty * 8 + (int)((i >> 3) & 7u), z = tz * 8 + (int)(i >> 6);
-    const uint64_t at = (uint64_t)x + (uint64_t)cx * ((uint64_t)y + (uint64_t)cy * (uint64_t)z);
+    const uint64_t at = hbm_index(x, y, z, cx, cz);
     const uint2 m = chunk_meta[i];
     meta[at] = m;
     if (m.x != kEmptySlot)
@@ -379,9 +380,9 @@ hipError_t layout_bricks(const uint32_t* src, uint32_t* dst, uint64_t nbricks, i
     }
     return hipGetLastError();
 }
-hipError_t chunk_tables(uint2* meta, uint32_t* coarse, const uint2* d_chunk_meta, int tx, int ty, int tz, int cx, int cy)
+hipError_t chunk_tables(uint2* meta, uint32_t* coarse, const uint2* d_chunk_meta, int tx, int ty, int tz, int cx, int cz)
 {
-    hipLaunchKernelGGL(k_chunk_tables, dim3(1), dim3(512), 0, 0, meta, coarse, d_chunk_meta, tx, ty, tz, cx, cy);
+    hipLaunchKernelGGL(k_chunk_tables, dim3(1), dim3(512), 0, 0, meta, coarse, d_chunk_meta, tx, ty, tz, cx, cz);
     return hipGetLastError();
 }
 
@@ -461,7 +462,7 @@ int build_world_on_device(vxrt_ctx* c, int generator, int X, int Y, int Z, int f
     }
     adopted = true;
     hipLaunchKernelGGL(k_pack_bricks, grid, block, 0, 0, (const uint4*)d_scratch, d_slot, d_ext, (uint4*)d_pool, d_meta,
-                       (uint32_t)(bw / 4), (uint32_t)ncells, cd[0], cd[1]);
+                       (uint32_t)(bw / 4), (uint32_t)ncells, cd[0], cd[1], cd[2]);
     WG_HIP(hipGetLastError());
     uint64_t nwords = (ncells + 31) / 32;
     hipLaunchKernelGGL(k_coarse_bits, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, 0, d_any, d_coarse, cd[0], cd[1], cd[2]);
