@@ -547,6 +547,25 @@ def test_device_world_builder_matches_oracle(eng, vxo, gen, shape, factor):
     assert np.array_equal(got["pool"], w.pool)
 
 
+@pytest.mark.parametrize("shape,factor", [((64, 128, 256), 8), ((256, 128, 384), 16), ((512, 256, 768), 32)])
+def test_uploaded_tables_come_back_in_the_reference_order(eng, vxo, shape, factor):
+    """The tables cross the C ABI in the reference's tiled bit order and live in HBM in the library's own linear order:
+    what vxrt_upload_world takes, vxrt_download_world gives back bit for bit (coarse bits, slots, extents, every brick),
+    on grids whose three dimensions differ, and the re-ordered world traces like the oracle's."""
+    vx, ctx, _ = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, *shape, factor)
+    _upload(ctx, w)
+    got = ctx.download_world()
+    assert np.array_equal(got["coarse_bits"], w.coarse_bits)
+    assert np.array_equal(got["brick_slot"], w.brick_slot)
+    assert np.array_equal(got["bounds"], w.bounds)
+    assert np.array_equal(got["pool"], w.pool)
+    rng = np.random.default_rng(shape[0] + factor)
+    o = (rng.random((20000, 3)) * np.array(shape)).astype(np.float32)
+    d = rng.normal(size=(20000, 3)).astype(np.float32)
+    _assert_batch_equal(ctx.Raytrace(o, d), w.trace_batch(o, d))
+
+
 def test_errors_are_reported_not_swallowed(eng, vxo):
     vx, ctx, torch = eng
     c2 = vx.Context(0)
