@@ -65,7 +65,22 @@ struct RayCounters {
 
 // float -> int as the hardware does it (v_cvt_i32_f32): truncation, saturating, NaN -> 0.  Spelled with the
 // intrinsic because a C cast is undefined out of range, and such values do occur (1/d overflows for denormal d).
+#ifndef VXRT_HOST_CHECK
+__device__ __forceinline__ int f2i(float v)
+{
+    // (spelled as the instruction: __float2int_rz compiles to v_trunc_f32 + v_cvt_i32_f32, and the conversion already
+    // truncates)
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+#else
 __device__ __forceinline__ int f2i(float v) { return __float2int_rz(v); }
+#endif
+// (float)f2i(v) == c for an integer-valued c in int range, as ONE instruction + the compare: truncf(v) is that float for
+// every finite v of int range, and beyond it (or for NaN) neither side of the original comparison can equal such a c --
+// except f2i(NaN) = 0 against c = 0, where the reference's own cast (cvttss2si: INT_MIN) says "different", as truncf does
+__device__ __forceinline__ bool trunc_equals(float v, float c) { return truncf(v) == c; }
 
 // Lane conditions as explicit wave masks: lane_mask(p) is the 64-bit mask of p over the wave (a v_cmp result as it
 // is), masks combine with & | ~ on the scalar unit, lane_test(m) reads this lane's bit back as a condition for a

@@ -279,13 +279,13 @@ struct WaveTracer {
         // brick miss: start = hitPosition / f; if the brick walk left the brick and start is still inside HitCell,
         // nudge all three components one ulp along the ray, and if that is not enough snap one axis to NextCell
         float sx = hp.x * W.inv_f, sy = hp.y * W.inv_f, sz = hp.z * W.inv_f;
-        const bool same1 = (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
+        const bool same1 = trunc_equals(sx, fx) & trunc_equals(sy, fy) & trunc_equals(sz, fz);  // HitCell.x == (int)start.x ..., :441-444
         const bool nudge = fine_miss & ((wf & WF_OOB) != 0u) & same1;
         const float ux = ulp_step(sx, d.x < 0), uy = ulp_step(sy, d.y < 0), uz = ulp_step(sz, d.z < 0);
         sx = nudge ? ux : sx;
         sy = nudge ? uy : sy;
         sz = nudge ? uz : sz;
-        const bool snap = nudge & (fx == (float)f2i(sx)) & (fy == (float)f2i(sy)) & (fz == (float)f2i(sz));
+        const bool snap = nudge & trunc_equals(sx, fx) & trunc_equals(sy, fy) & trunc_equals(sz, fz);
         // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from the clamped HitCell by
         // one when the walk started on a far face (edge rule)
         const int nca = LDS_COLD ? (int)(box_codes >> 3) : nc_axis;
@@ -301,9 +301,17 @@ struct WaveTracer {
         sx = (snap & snap_x) ? sx + gx : sx;  // (a branch around this rare case measured no better)
         sy = (snap & snap_y) ? sy + gy : sy;
         sz = (snap & snap_z) ? sz + gz : sz;
-        cput(CF_START_X, start.x, fine_miss ? sx : cget(CF_START_X, start.x));
-        cput(CF_START_Y, start.y, fine_miss ? sy : cget(CF_START_Y, start.y));
-        cput(CF_START_Z, start.z, fine_miss ? sz : cget(CF_START_Z, start.z));
+        if (LDS_COLD) {
+            if (fine_miss) {  // (plain stores under one exec mask: no read-modify-write of the three cells)
+                cold[CF_START_X * 64] = __float_as_uint(sx);
+                cold[CF_START_Y * 64] = __float_as_uint(sy);
+                cold[CF_START_Z * 64] = __float_as_uint(sz);
+            }
+        } else {
+            start.x = fine_miss ? sx : start.x;
+            start.y = fine_miss ? sy : start.y;
+            start.z = fine_miss ? sz : start.z;
+        }
         const bool restart = fine_miss && total_ < (LDS_COLD ? (int)(ray_codes >> 7) : max_steps);  // the while condition, checked only here (:386)
         const bool go = enter | restart;
         // both continuations (enter the brick / restart the coarse walk) share ONE begin_walk: its three IEEE
