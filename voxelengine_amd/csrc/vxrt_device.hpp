@@ -77,6 +77,19 @@ __device__ __forceinline__ int f2i(float v)
 #else
 __device__ __forceinline__ int f2i(float v) { return __float2int_rz(v); }
 #endif
+// a cell coordinate clamped into [0, top] (top >= 0): the median of (v, 0, top), one instruction.  The probes read the
+// occupancy word of the clamped cell unconditionally -- in range it is the cell (or, under the edge rule, its clamped
+// neighbour, :242-244), out of range any valid word will do, its bit is ignored
+#ifndef VXRT_HOST_CHECK
+__device__ __forceinline__ int clamp_cell(int v, int top)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "v"(top));
+    return r;
+}
+#else
+__device__ __forceinline__ int clamp_cell(int v, int top) { return v < 0 ? 0 : (v > top ? top : v); }
+#endif
 // (float)f2i(v) == c for an integer-valued c in int range, as ONE instruction + the compare: truncf(v) is that float for
 // every finite v of int range, and beyond it (or for NaN) neither side of the original comparison can equal such a c --
 // except f2i(NaN) = 0 against c = 0, where the reference's own cast (cvttss2si: INT_MIN) says "different", as truncf does

@@ -389,11 +389,9 @@ struct WaveTracer {
         // 0 <= cell < dim + pad on all three axes: unsigned compares (a negative cell is a huge unsigned)
         const lanemask_t in = lane_mask((uint32_t)cell_x < (uint32_t)lim_x) & lane_mask((uint32_t)cell_y < (uint32_t)lim_y) &
                               lane_mask((uint32_t)cell_z < (uint32_t)lim_z);
-        // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); an out-of-range
-        // lane reads word 0 instead, so the unconditional load below always has a valid address
-        const int qx = min(cell_x, dm1_x), qy = min(cell_y, dm1_y), qz = min(cell_z, dm1_z);
-        const uint32_t idx_raw = cell_index(qx, qy, qz, row, slice);
-        const uint32_t idx = lane_test(in) ? idx_raw : 0u;
+        // lookups use the cell clamped to dim-1 (:242-244; matters only under the edge rule); clamped at 0 as well, so
+        // that the unconditional load below has a valid address for an out-of-range lane too (its bit is ignored)
+        const uint32_t idx = cell_index(clamp_cell(cell_x, dm1_x), clamp_cell(cell_y, dm1_y), clamp_cell(cell_z, dm1_z), row, slice);
         // MASKED_LOAD: only walking lanes load.  In the render kernels the load is unconditional (parked lanes re-read
         // their last word from L1/L2; the exec-mask branch around the load costs 3.6 % of the frame rate); for a batch
         // of incoherent rays, where every request is an HBM miss, masking it is worth +23 % (tools/batch_probe.py)
@@ -465,8 +463,7 @@ struct WaveTracer {
         const lanemask_t w1 = lane_mask(st == ST_WALK);
         const lanemask_t in1 = lane_mask((uint32_t)cell_x < (uint32_t)lim_x) & lane_mask((uint32_t)cell_y < (uint32_t)lim_y) &
                                lane_mask((uint32_t)cell_z < (uint32_t)lim_z);
-        const uint32_t idx1_raw = cell_index(min(cell_x, dm1_x), min(cell_y, dm1_y), min(cell_z, dm1_z), row, slice);
-        const uint32_t idx1 = lane_test(in1) ? idx1_raw : 0u;
+        const uint32_t idx1 = cell_index(clamp_cell(cell_x, dm1_x), clamp_cell(cell_y, dm1_y), clamp_cell(cell_z, dm1_z), row, slice);
         uint32_t word1 = 0u;
         if (!MASKED_LOAD || st == ST_WALK)
             word1 = bits[idx1 >> 5];
@@ -485,8 +482,7 @@ struct WaveTracer {
         const int nx = cell_x + (on0 ? 2 * up_x - 1 : 0), ny = cell_y + (on1 ? 2 * up_y - 1 : 0), nz = cell_z + (on2 ? 2 * up_z - 1 : 0);
         const lanemask_t in2 = lane_mask((uint32_t)nx < (uint32_t)lim_x) & lane_mask((uint32_t)ny < (uint32_t)lim_y) &
                                lane_mask((uint32_t)nz < (uint32_t)lim_z);
-        const uint32_t idx2_raw = cell_index(min(nx, dm1_x), min(ny, dm1_y), min(nz, dm1_z), row, slice);
-        const uint32_t idx2 = lane_test(in2) ? idx2_raw : 0u;
+        const uint32_t idx2 = cell_index(clamp_cell(nx, dm1_x), clamp_cell(ny, dm1_y), clamp_cell(nz, dm1_z), row, slice);
         uint32_t word2 = 0u;
         if (!MASKED_LOAD || st == ST_WALK)
             word2 = bits[idx2 >> 5];
