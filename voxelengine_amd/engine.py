@@ -286,9 +286,10 @@ class Context:
 
     def set_kernel_variant(self, variant: int) -> None:
         """0 = wave-level state machine, 1 = straightforward per-lane loops (A/B, cross-check), 2 = persistent
-        waves with a pixel queue, 3 = persistent waves with the pixel chains pooled in LDS, 4 = default (3 for
-        multi-view launches, 2 for single-view ones), 5 = persistent waves with the cold state (tracer fields only the parked
-        phases touch, the pixel's chain state) in LDS, 5 waves per SIMD."""
+        waves with a pixel queue, 3 = persistent waves with the pixel chains pooled in LDS, 5 = persistent waves with the
+        cold state (tracer fields only the parked phases touch, the pixel's chain state) in LDS at 5 waves per SIMD,
+        4 = default: picked per launch -- 5 for multi-view and large single-view launches, 2 for small ones
+        (kernel_for_launch tells which)."""
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
         self.kernel_variant = int(variant)
 
