@@ -321,7 +321,7 @@ int vxrt_kernel_for_launch(const vxrt_ctx* c, uint32_t width, uint32_t height, c
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
     if (!c || variant < 0 || variant > 5)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default: 3 for multi-view launches, else 2) or 5 (persistent, cold state in LDS, 5 waves per SIMD)");
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default: 5 or 2, picked per launch) or 5 (persistent, cold state in LDS, 5 waves per SIMD)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }

@@ -90,7 +90,7 @@ class Context:
         N.check(self._L.vxrt_create(device, C.byref(h)))
         self._h = h
         self.device = device
-        self.kernel_variant = 4  # the library's default (persistent waves; pool kernel for multi-view launches)
+        self.kernel_variant = 4  # the library's default (persistent waves, the kernel picked per launch)
 
     def close(self):
         if getattr(self, "_h", None):
