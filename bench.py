@@ -82,6 +82,10 @@ def main():
     if args.gpus > 1 and not launcher.under_launcher():
         # started as a plain program: become the launcher.  N fresh children of this script, one per GPU, are started
         # BEFORE anything here touches the GPU; rank 0's one JSON line is relayed, a failing rank fails the job.
+        # The library is (re)built HERE, once, before any rank exists: the cross-compile needs no GPU, and N ranks that all
+        # find a stale tree would otherwise queue up behind build_lib's lock.
+        from voxelengine_amd import build as _build
+        _build.build_lib()
         rc, out = launcher.launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:])
         lines = [ln for ln in out.splitlines() if ln.strip()]
         if lines:

@@ -109,12 +109,14 @@ int vxrt_download_world(vxrt_ctx *ctx, uint32_t *coarse_bits, uint32_t *brick_sl
 
 /* ---- brickmap file.  The reference rebuilds its world at every start (VoxelApp/main.cu:41-49:
  * CreateVoxels + GenerateLowresVoxelBuffer, minutes at 8k scale on its host threads); a built brickmap can be
- * kept instead.  Layout (little endian): 104-byte header {"VXBRKMAP", u32 version = 1, u32 header bytes,
+ * kept instead.  Layout (little endian): 120-byte header {"VXBRKMAP", u32 version = 2, u32 header bytes,
  * i32 factor, i32 cdims[3], u64 ncells, u64 nslots, u64 bytes of the three streams, u64 word sums of the three
  * streams, u64 sums of the running word sums of the three streams (position-sensitive)}, then the streams as they lie in HBM: coarse_bits (as in vxrt_world_desc), one 8-byte
  * record per cell {u32 pool slot or VXRT_EMPTY_SLOT, u32 extents: min x,y,z then max x,y,z, 5 bits each from bit 0}
  * in the order of coarse_bits, and the pool.  Loading validates sizes, sums and the cell table against the coarse
- * bits, and streams through a 64 MiB staging buffer. */
+ * bits, and streams through a 64 MiB staging buffer.  Version 1 files (104-byte header, plain word sums only; written
+ * by the first round's builds) are refused: regenerate them with vxrt_save_world.  Shapes: every coarse dimension a
+ * positive multiple of 8, at most 65535, with cx * cz < 2^24 and cx * cy * cz < 2^32 (32-bit cell indices). */
 int vxrt_save_world(vxrt_ctx *ctx, const char *path);
 int vxrt_load_world(vxrt_ctx *ctx, const char *path);
 /* header of a brickmap file (no GPU needed); hbm_bytes = bytes the three streams will occupy */
@@ -258,6 +260,13 @@ int vxrt_deinterleave_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, int3
  * convention: miss -> point = +inf; normal (step direction, zero on a miss) and
  * steps always written.  d_hit / d_voxel (optional) are this build's additions:
  * hit flag and global hit voxel index x + X*(y + Y*z), -1 on a miss. */
+/* RAY VALIDITY (defined by this build; the reference leaves it undefined): a ray is valid when its origin's components
+ * are finite (their absolute sum is a finite binary32) and the squared length of its direction, evaluated in binary32, is
+ * positive and finite -- i.e. normalize(direction) is a vector of finite numbers.  NaN or infinite components, the zero
+ * direction, and directions so short or long that the squared length leaves the binary32 range make Raytrace's prologue
+ * (VolumeRaytracer.cu:359-367) produce NaN, which the reference then casts to int (undefined).  An INVALID ray of a batch
+ * is not traced: its result is a miss with 0 steps (point = +inf, normal = 0, d_hit = 0, d_voxel = -1); it is counted as
+ * a ray.  vxrt_render / vxrt_render_views return VXRT_ERR_INVALID for a camera with a non-finite component. */
 int vxrt_trace_batch(vxrt_ctx *ctx, const float *d_origins, const float *d_dirs, uint64_t n, float *d_pos,
                      float *d_normal, int32_t *d_steps, uint8_t *d_hit, int64_t *d_voxel,
                      vxrt_frame_stats *stats_or_null, void *stream);

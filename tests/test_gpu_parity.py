@@ -82,6 +82,59 @@ def test_trace_batch_persistent_queue(eng, vxo, n):
         ctx.close()
 
 
+def test_invalid_rays_are_defined_misses_and_a_bad_camera_is_rejected(eng, vxo):
+    """Ray validity at the C ABI (include/vxrt.h): a ray with a NaN / infinite component, the zero direction, or a
+    direction whose squared length leaves the binary32 range is not traced; its result is a miss with 0 steps.  The valid
+    rays around it are unaffected (equal to the oracle), in every batch kernel -- straightforward, wave state machine and
+    the persistent queue.  A camera with a non-finite component is an error, not a frame."""
+    import os
+    vx, ctx0, torch = eng
+    os.environ["VXRT_WAVES_PER_CU"] = "1"   # small persistent grid: the 300 000-ray batch below takes the queue kernel
+    try:
+        ctx = vx.Context(0)
+    finally:
+        del os.environ["VXRT_WAVES_PER_CU"]
+    try:
+        w = helpers.random_voxel_world(vxo, (128, 128, 128), 16, 0.004, 33)
+        _upload(ctx, w)
+        n = 300000
+        o, d = helpers.mixed_rays(w.dims, n, 11)
+        bad = np.zeros(n, bool)
+        nan, inf = np.float32(np.nan), np.float32(np.inf)
+        poison = [("o", 0, nan), ("o", 2, inf), ("o", 1, -inf), ("d", 0, nan), ("d", 1, inf), ("d", None, 0.0),
+                  ("d", None, 1e-30), ("d", None, 1e30)]
+        for k, (what, comp, val) in enumerate(poison):
+            idx = np.arange(7 + k * 13, n, 997)
+            arr = o if what == "o" else d
+            if comp is None:
+                arr[idx] = (np.sign(arr[idx]) + (arr[idx] == 0)) * np.float32(val)   # all three components that small / large
+            else:
+                arr[idx, comp] = val
+            bad[idx] = True
+        good = ~bad
+        cpu = w.trace_batch(o[good], d[good])
+        for variant in (2, 0, 1):
+            ctx.set_kernel_variant(variant)
+            g = ctx.Raytrace(o, d, want_stats=True)
+            assert g["stats"].primary_rays == n
+            sub = {k: g[k][good] for k in ("hit", "steps", "voxel", "hitPoint", "normal")}
+            _assert_batch_equal(sub, cpu)
+            assert not g["hit"][bad].any() and not g["steps"][bad].any() and (g["voxel"][bad] == -1).all(), variant
+            assert np.isposinf(g["hitPoint"][bad]).all() and not g["normal"][bad].any(), variant
+        W, H = 64, 48
+        fb = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        pos, f, u, r = helpers.camera("A", w.dims, vxo)
+        for which in range(4):
+            args = [list(pos), list(f), list(u), list(r)]
+            args[which][which % 3] = float("nan") if which % 2 == 0 else float("inf")
+            with pytest.raises(vx.VxrtError):
+                ctx.RenderScreen(W, H, fb, *args)
+        ctx.RenderScreen(W, H, fb, pos, f, u, r)   # and the context still renders afterwards
+        torch.cuda.synchronize()
+    finally:
+        ctx.close()
+
+
 def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     vx, ctx, _ = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
@@ -95,7 +148,7 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6])
 def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
     """Variants: 0 wave state machine (one lane per pixel), 1 straightforward per-lane loops, 2 persistent waves
     with a pixel queue.  All give the oracle's bits, in every render mode."""
@@ -424,7 +477,7 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 0])
+@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 0])
 def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
     """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).
     Every view must be byte for byte the frame RenderScreen produces for it -- frame, hit-index AOV and colour AOV --

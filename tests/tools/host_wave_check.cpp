@@ -69,6 +69,12 @@ int main(int argc, char** argv)
         bool same2 = t2.hit == t.hit && t2.steps == t.steps && memcmp(&t2.normal, &t.normal, 12) == 0 && c2.coarse_probes == c.coarse_probes &&
                      c2.brick_entries == c.brick_entries && c2.fine_probes == c.fine_probes;
         if (t.hit) same2 = same2 && memcmp(&t2.pos, &t.pos, 12) == 0 && t2.vx == t.vx && t2.vy == t.vy && t2.vz == t.vz;
+        // ... and so must a ray that starts from its prepared record (prepare_ray + begin_prepared: the traversal kernel's start)
+        TraceResult t3; RayCounters c3{0, 0, 0};
+        trace_wave<true, false, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t3, c3, nullptr, cold_column, true);
+        same2 = same2 && t3.hit == t.hit && t3.steps == t.steps && memcmp(&t3.normal, &t.normal, 12) == 0 && c3.coarse_probes == c.coarse_probes &&
+                c3.brick_entries == c.brick_entries && c3.fine_probes == c.fine_probes;
+        if (t.hit) same2 = same2 && memcmp(&t3.pos, &t.pos, 12) == 0 && t3.vx == t.vx && t3.vy == t.vy && t3.vz == t.vz;
         bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries && c.fine_probes == st.fine_probes;
         if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
         ok = ok && same2;

@@ -14,6 +14,8 @@
 #define __launch_bounds__(x)
 struct uint2 { uint32_t x, y; };
 static inline uint2 make_uint2(uint32_t a, uint32_t b) { return uint2{a, b}; }
+struct uint4 { uint32_t x, y, z, w; };
+static inline uint4 make_uint4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return uint4{a, b, c, d}; }
 static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
 static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 typedef unsigned long long lanemask_t;  // one lane on the host: bit 0

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/abc_$1; shift
 mkdir -p $OUT
 for w in ${WORKLOADS:-c2_1k_1080p_primary c3_f8_variant c4_8k_4k_shadow_bounce c5_16k_4k_shadow_bounce}; do
   for v in "$@"; do
-    VXRT_VARIANT=$v python3 $R/bench.py --cpu-baseline off --workload $w --steps ${STEPS:-6} --warmup 1 > $OUT/${w}_v$v.json 2> $OUT/${w}_v$v.err || { echo "$w v$v failed"; tail -3 $OUT/${w}_v$v.err; continue; }
+    VXRT_VARIANT=$v python3 $R/bench.py --cpu-baseline off --workload $w --steps ${STEPS:-6} --warmup 1 > $OUT/${w}_v$v.json 2> $OUT/${w}_v$v.err || { echo "$w v$v failed"; tail -20 $OUT/${w}_v$v.err; echo "stopping: no further GPU run behind a failed one"; exit 1; }
     python3 - "$OUT/${w}_v$v.json" "$w v$v" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

@@ -10,7 +10,7 @@ run() {
   IFS=: read -r var tag wpc <<< "$1"
   local lib=$R/voxelengine_amd/csrc/libvxrt.so
   [ -n "$tag" ] && [ "$tag" != base ] && lib=$R/voxelengine_amd/csrc/libvxrt_$tag.so
-  VXRT_VARIANT=$var VXRT_LIB=$lib VXRT_WAVES_PER_CU=$wpc python3 $R/bench.py --cpu-baseline off ${BENCH_ARGS:-} > $OUT/$2.json 2> $OUT/$2.err || { echo "$1 failed"; tail -3 $OUT/$2.err; return 1; }
+  VXRT_VARIANT=$var VXRT_LIB=$lib VXRT_WAVES_PER_CU=$wpc python3 $R/bench.py --cpu-baseline off ${BENCH_ARGS:-} > $OUT/$2.json 2> $OUT/$2.err || { echo "$1 failed"; tail -20 $OUT/$2.err; echo "stopping: no further GPU run behind a failed one (full log: $OUT/$2.err)"; exit 1; }
   python3 - "$OUT/$2.json" "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

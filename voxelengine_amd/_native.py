@@ -98,8 +98,10 @@ def load() -> C.CDLL:
         pass
     path = os.environ.get("VXRT_LIB", _build.LIB_PATH)  # VXRT_LIB: A/B builds of the same library (tools/)
     if path == _build.LIB_PATH:
-        # staleness check against every source of the library (mtime; runs make only when something is newer), done
-        # here, before this process has touched the GPU, so the make child is harmless
+        # Content-hash staleness check against every source of the library; make/hipcc run only when it is stale, under a
+        # lock, into a temporary file renamed into place (build.build_lib).  Normally this process has not touched the GPU
+        # yet, so the make child is harmless; under a profiler (whose preload initialises the GPU before Python starts)
+        # build beforehand and set VXRT_SKIP_STALE_CHECK=1 so that no child is started here.
         _build.build_lib(force=bool(os.environ.get("VXRT_REBUILD")))
     if not os.path.exists(path):
         raise RuntimeError(f"libvxrt.so not found at {path}; run __graft_entry__.build()")
@@ -145,10 +147,8 @@ def load() -> C.CDLL:
     L.vxrt_stream_close.argtypes = [C.c_void_p]
     L.vxrt_trace_batch_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]
-    for name in EXPORTS:
-        fn = getattr(L, name)
-        if fn.restype is C.c_int and name not in ("vxrt_abi_version",):
-            pass
+    for name in EXPORTS:  # every symbol the header declares must resolve
+        getattr(L, name)
     _LIB = L
     return L
 

@@ -40,11 +40,37 @@ def lib_sources() -> list[str]:
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 cross-compiles without a GPU."""
-    if force or _stale(LIB_PATH, lib_sources()):
-        subprocess.check_call(["make", "-C", CSRC, "-B", "libvxrt.so"], stdout=None if verbose else subprocess.DEVNULL)
-        with open(LIB_PATH + ".srchash", "w") as f:
-            f.write(_digest(lib_sources()) + "\n")
+    """hipcc --offload-arch=gfx950 cross-compiles without a GPU.
+
+    Safe when several ranks import the package at once on a stale tree (a fresh snapshot, or after a source edit): the
+    build runs under an exclusive lock on csrc/.build.lock, into a temporary name that is renamed over libvxrt.so when it
+    is complete, and the stamp is written last, still under the lock -- a sibling either finds the finished library or
+    waits for the lock and then finds it.  VXRT_SKIP_STALE_CHECK=1: never build (for processes started under a profiler,
+    whose preload has initialised the GPU before Python runs: no make/hipcc children there; build beforehand)."""
+    import fcntl
+
+    if os.environ.get("VXRT_SKIP_STALE_CHECK") and os.path.exists(LIB_PATH) and not force:
+        return LIB_PATH
+    if not force and not _stale(LIB_PATH, lib_sources()):
+        return LIB_PATH
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force or _stale(LIB_PATH, lib_sources()):  # (again: a sibling may have built it while this one waited)
+                tmp = "libvxrt.so.tmp.%d" % os.getpid()
+                try:
+                    subprocess.check_call(["make", "-C", CSRC, "-B", tmp, "OUT=" + tmp],
+                                          stdout=None if verbose else subprocess.DEVNULL)
+                    os.replace(os.path.join(CSRC, tmp), LIB_PATH)
+                finally:
+                    if os.path.exists(os.path.join(CSRC, tmp)):
+                        os.unlink(os.path.join(CSRC, tmp))
+                stamp = LIB_PATH + ".srchash"
+                with open(stamp + ".tmp", "w") as f:
+                    f.write(_digest(lib_sources()) + "\n")
+                os.replace(stamp + ".tmp", stamp)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 

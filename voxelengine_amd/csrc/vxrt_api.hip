@@ -17,7 +17,7 @@
 #include <vector>
 
 namespace vxrt {
-hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream, const TsArgs* ts);
 int resolve_render_variant(const RenderArgs& A, int variant);
 hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
@@ -77,6 +77,15 @@ struct vxrt_ctx {
     vxrt::ViewArgs* d_views = nullptr;
     std::atomic<unsigned> view_seq{0};
     hipEvent_t views_busy[16] = {};
+    // Workspaces of the traversal/shading pipeline (variant 6, vxrt_ts.hpp): ray queues, results and pixel chain state in HBM.
+    // A ring, like the queue heads: a launch takes the next entry, grows it if its frame needs more, and waits for the launch
+    // that used it last if that one is still in flight (so two frames in flight on two streams never share queues).
+    struct TsSlot {
+        void* mem = nullptr;
+        size_t bytes = 0;
+        hipEvent_t busy = nullptr;
+    } ts_ring[3];
+    std::atomic<unsigned> ts_seq{0};
     int batch_max_steps = vxrt::kMaxSteps;  // Raytrace's maxSteps for the batch API (vxrt_set_batch_max_steps)
     struct StreamState* stream = nullptr;   // chunk streaming (vxrt_stream_*), or NULL
 };
@@ -199,6 +208,51 @@ static hipError_t ring_release(hipEvent_t& ev, hipStream_t stream, bool capturin
     return hipEventRecord(ev, stream);
 }
 
+// Lease a traversal/shading workspace for one launch of `A` (variant 6): carve the ring entry into the pipeline's arrays.
+static int ts_lease(vxrt_ctx* c, const RenderArgs& A, hipStream_t stream, TsArgs& S, unsigned& slot_index, bool& capturing)
+{
+    const unsigned long long nv = A.nviews ? A.nviews : 1u;
+    const unsigned long long tiles = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u);
+    const unsigned long long slots = tiles * 64ull * nv;          // queue capacity: no generation has more rays than pixels
+    const unsigned long long pixels = (unsigned long long)A.width * A.launch_rows * nv;
+    auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
+    const unsigned long long b_rays = up(slots * 64ull), b_pix = up(slots * 4ull), b_res = up(slots * 16ull),
+                             b_vox = A.want_hit_aov ? up(slots * 8ull) : 0ull, b_state = up(pixels * 32ull),
+                             b_cnt = up(2ull * (kTsMaxGenerations + 1u) * sizeof(unsigned int));
+    const unsigned long long need = 2 * b_rays + 2 * b_pix + b_res + b_vox + b_state + b_cnt;
+    slot_index = c->ts_seq.fetch_add(1u) % 3u;
+    vxrt_ctx::TsSlot& T = c->ts_ring[slot_index];
+    hipError_t e = ring_acquire(T.busy, stream, capturing);
+    if (e != hipSuccess)
+        return fail(VXRT_ERR_HIP, std::string("workspace ring: ") + hipGetErrorString(e));
+    if (T.bytes < need) {
+        if (capturing)
+            return fail(VXRT_ERR_INVALID, "the traversal/shading workspace must be sized before stream capture: render the frame once first");
+        if (T.mem)
+            (void)hipFree(T.mem);  // (the entry's last launch has finished: ring_acquire waited for it)
+        T.mem = nullptr;
+        T.bytes = 0;
+        e = hipMalloc(&T.mem, need);
+        if (e != hipSuccess)
+            return fail(VXRT_ERR_NOMEM, std::string("traversal/shading workspace: ") + hipGetErrorString(e));
+        T.bytes = need;
+    }
+    unsigned char* at = static_cast<unsigned char*>(T.mem);
+    auto take = [&](unsigned long long b) { unsigned char* r = at; at += b; return r; };
+    S.rays[0] = reinterpret_cast<uint4*>(take(b_rays));
+    S.rays[1] = reinterpret_cast<uint4*>(take(b_rays));
+    S.pix[0] = reinterpret_cast<uint32_t*>(take(b_pix));
+    S.pix[1] = reinterpret_cast<uint32_t*>(take(b_pix));
+    S.res = reinterpret_cast<uint4*>(take(b_res));
+    S.res_voxel = b_vox ? reinterpret_cast<long long*>(take(b_vox)) : nullptr;
+    S.pstate = reinterpret_cast<uint4*>(take(b_state));
+    S.counts = reinterpret_cast<unsigned int*>(take(b_cnt));
+    S.tickets = S.counts + (kTsMaxGenerations + 1u);
+    S.pixels_per_view = A.width * A.launch_rows;
+    S.slots_per_view = (uint32_t)(tiles * 64ull);
+    return VXRT_OK;
+}
+
 // Default hand-out order of the persistent kernel's tile queue: expected-longest ray chains first, so that what is
 // still in flight when the queue runs dry is cheap.  The cost proxy needs the camera only: the elevation of the
 // centre ray of each 8-pixel tile row in a Y-up world -- rays just below the horizon travel farthest, rays
@@ -267,7 +321,7 @@ int vxrt_create(int device, vxrt_ctx** out)
         e = hipGetDeviceProperties(&prop, device);
         c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
         if (const char* v = getenv("VXRT_VARIANT"))                       // A/B of the render kernels (tools/)
-            if (atoi(v) >= 0 && atoi(v) <= 5)
+            if (atoi(v) >= 0 && atoi(v) <= 6)
                 c->kernel_variant = atoi(v);
         if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments only
             if (atoi(e) > 0 && atoi(e) <= 32)
@@ -290,6 +344,10 @@ int vxrt_destroy(vxrt_ctx* c)
     vxrt::free_world(c);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_views) (void)hipFree(c->d_views);
+    for (auto& t : c->ts_ring) {
+        if (t.mem) (void)hipFree(t.mem);
+        if (t.busy) (void)hipEventDestroy(t.busy);
+    }
     for (hipEvent_t& e : c->counter_busy)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t& e : c->views_busy)
@@ -320,8 +378,8 @@ int vxrt_kernel_for_launch(const vxrt_ctx* c, uint32_t width, uint32_t height, c
 
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
-    if (!c || variant < 0 || variant > 5)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default: 5 or 2, picked per launch) or 5 (persistent, cold state in LDS, 5 waves per SIMD)");
+    if (!c || variant < 0 || variant > 6)
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default, picked per launch), 5 (persistent, cold state in LDS, 5 waves per SIMD) or 6 (traversal / shading kernels over ray queues)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }
@@ -576,9 +634,15 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     if (fl->strip_count > 1 && (fl->strip_rows <= 0 || fl->strip_index < 0 || fl->strip_index >= fl->strip_count))
         return fail(VXRT_ERR_INVALID, "bad strip sharding");
     const unsigned n = nviews ? nviews : 1u;
-    for (unsigned v = 0; v < n; ++v)
+    for (unsigned v = 0; v < n; ++v) {
         if (!views[v].d_fb)
             return fail(VXRT_ERR_INVALID, "a view has no framebuffer");
+        // ray validity (include/vxrt.h): a camera with a non-finite component would hand every pixel an invalid ray
+        for (int a = 0; a < 3; ++a)
+            if (!std::isfinite(views[v].origin[a]) || !std::isfinite(views[v].fwd[a]) || !std::isfinite(views[v].up[a]) ||
+                !std::isfinite(views[v].right[a]))
+                return fail(VXRT_ERR_INVALID, "camera origin / forward / up / right must be finite numbers");
+    }
     if (fl->d_accum && nviews != 0)
         return fail(VXRT_ERR_INVALID, "temporal accumulation (d_accum) is per view: use vxrt_render");
     if (fl->d_accum && (reinterpret_cast<uintptr_t>(fl->d_accum) & 15u))
@@ -667,8 +731,19 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
             bool capturing = false;
             VX_HIP(vxrt::ring_acquire(c->counter_busy[slot], stream, capturing));
             A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + slot;
-            VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
+            vxrt::TsArgs ts;
+            unsigned ts_slot = 0;
+            bool ts_cap = false;
+            const bool use_ts = vxrt::resolve_render_variant(A, c->kernel_variant) == 6;
+            if (use_ts) {
+                const int rc = vxrt::ts_lease(c, A, stream, ts, ts_slot, ts_cap);
+                if (rc)
+                    return rc;
+            }
+            VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream, use_ts ? &ts : nullptr));
             VX_HIP(hipGetLastError());
+            if (use_ts)
+                VX_HIP(vxrt::ring_release(c->ts_ring[ts_slot].busy, stream, ts_cap));
             VX_HIP(vxrt::ring_release(c->counter_busy[slot], stream, capturing));
         }
         return VXRT_OK;
@@ -702,8 +777,19 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     A.views = slot;
     A.nviews = n;
     A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + cslot;
-    VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
+    vxrt::TsArgs ts;
+    unsigned ts_slot = 0;
+    bool ts_cap = false;
+    const bool use_ts = vxrt::resolve_render_variant(A, c->kernel_variant) == 6;
+    if (use_ts) {
+        const int rc = vxrt::ts_lease(c, A, stream, ts, ts_slot, ts_cap);
+        if (rc)
+            return rc;
+    }
+    VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream, use_ts ? &ts : nullptr));
     VX_HIP(hipGetLastError());
+    if (use_ts)
+        VX_HIP(vxrt::ring_release(c->ts_ring[ts_slot].busy, stream, ts_cap));
     VX_HIP(vxrt::ring_release(c->views_busy[vslot], stream, capturing));
     VX_HIP(vxrt::ring_release(c->counter_busy[cslot], stream, capturing));
     return VXRT_OK;

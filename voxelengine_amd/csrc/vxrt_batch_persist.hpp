@@ -129,7 +129,22 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
                 const unsigned long long j = my_ray;
                 const f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
                 const f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
-                T.begin_ray(W, o, d, B.max_steps);
+                if (ray_valid(o, d)) {
+                    T.begin_ray(W, o, d, B.max_steps);
+                } else {  // include/vxrt.h, ray validity: not traced, its result is a miss with 0 steps, written here
+                    B.pos[3 * j] = kInf;
+                    B.pos[3 * j + 1] = kInf;
+                    B.pos[3 * j + 2] = kInf;
+                    B.normal[3 * j] = 0.0f;
+                    B.normal[3 * j + 1] = 0.0f;
+                    B.normal[3 * j + 2] = 0.0f;
+                    B.steps[j] = 0;
+                    if (B.hit)
+                        B.hit[j] = 0;
+                    if (B.voxel)
+                        B.voxel[j] = -1ll;
+                    my_ray = kNone;  // the lane stays in ST_DONE and asks for its next ray in the next ray-finished phase
+                }
             }
             if (drained && T.st == ST_DONE && my_ray == kNone)
                 T.st = ST_IDLE;

@@ -194,6 +194,19 @@ __device__ __forceinline__ bool ray_box(f3 s, f3 d, f3 bmin, f3 bmax, f3& p, f3&
     return true;
 }
 
+// Ray validity at the C ABI (include/vxrt.h, "ray validity"): the origin's components are finite (their absolute sum is
+// a finite binary32) and the direction's squared length, evaluated in binary32 as normalize does (helper_math.h:1325-1329),
+// is positive and finite -- i.e. normalize(ray) is a vector of finite numbers.  Anything else (NaN, infinities, the zero
+// vector, a direction so short or so long that its squared length leaves the binary32 range) makes Raytrace's prologue
+// produce NaN or infinite directions in the reference (VolumeRaytracer.cu:359-367), from where its behaviour is
+// undefined (float -> int casts of NaN); this build defines the result of such a ray instead: a miss with 0 steps.
+__device__ __forceinline__ bool ray_valid(f3 o, f3 d)
+{
+    const float dd = dot3(d, d);
+    const float mag = fabsf(o.x) + fabsf(o.y) + fabsf(o.z);
+    return mag < kInf && dd > 0.0f && dd < kInf;  // (every comparison is false for NaN)
+}
+
 struct WalkResult {
     bool hit, oob;
     int hx, hy, hz;     // HitCell (clamped cell of the last in-range probe)

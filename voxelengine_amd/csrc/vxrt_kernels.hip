@@ -4,6 +4,7 @@
 #include "vxrt_kernels.hpp"
 #include "vxrt_wave.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace vxrt {
@@ -269,7 +270,15 @@ __global__ __launch_bounds__(256) void k_trace_batch(BatchArgs B)
         f3 o = mk3(B.origins[3 * i], B.origins[3 * i + 1], B.origins[3 * i + 2]);
         f3 d = mk3(B.dirs[3 * i], B.dirs[3 * i + 1], B.dirs[3 * i + 2]);
         TraceResult t;
-        trace_direct(B.W, B.max_steps, o, d, t, cnt);
+        if (ray_valid(o, d)) {
+            trace_direct(B.W, B.max_steps, o, d, t, cnt);
+        } else {  // defined by this build (include/vxrt.h, ray validity): a miss with 0 steps
+            t.hit = false;
+            t.steps = 0;
+            t.normal = mk3(0, 0, 0);
+            t.pos = mk3(kInf, kInf, kInf);
+            t.vx = t.vy = t.vz = 0;
+        }
         rays = 1;
         hits = t.hit ? 1 : 0;
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);  // dispatch, VolumeRaytracer.cu:105-113
@@ -524,7 +533,8 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
     f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
     f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
     TraceResult t;
-    trace_wave<STATS, true>(B.W, B.max_steps, live, o, d, t, cnt, (STATS && i == 0) ? B.dbg_trace : nullptr);
+    // an invalid ray (include/vxrt.h, ray validity) is not traced: the tracer's initial state reads as a miss with 0 steps
+    trace_wave<STATS, true>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, cnt, (STATS && i == 0) ? B.dbg_trace : nullptr);
     if (live) {
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
         B.pos[3 * i] = p.x;
@@ -561,8 +571,56 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 #include "vxrt_persist_lds.hpp"
 #include "vxrt_pool.hpp"
 #include "vxrt_batch_persist.hpp"
+#include "vxrt_ts.hpp"
 
 namespace vxrt {
+
+// generations of a traversal/shading launch: primary, shadow, bounce samples (each possibly followed by its second bounce)
+int ts_generations(const RenderArgs& A)
+{
+    if (A.mode != 0)
+        return 1;  // the debug view stores every pixel after its primary ray
+    return 1 + (A.shadow ? 1 : 0) + (A.bounce_samples > 0 ? A.bounce_samples * (A.bounce_depth >= 2 ? 2 : 1) : 0);
+}
+
+// Variant 6: the wavefront pipeline of vxrt_ts.hpp.  One stream, kernels in generation order:
+//   gen | T(0) S(0) | T(1) S(1) | ... ; the queue lengths stay on the device (T and S read counts[g]), no host round trip.
+hipError_t launch_render_ts(const RenderArgs& A, const TsArgs& S, bool stats, hipStream_t stream)
+{
+    const int gens = ts_generations(A);
+    hipError_t e = hipMemsetAsync(S.counts, 0, 2u * (kTsMaxGenerations + 1u) * sizeof(unsigned int), stream);  // counts + tickets
+    if (e != hipSuccess)
+        return e;
+    const unsigned nviews = A.nviews ? A.nviews : 1u;
+    const unsigned long long slots = (unsigned long long)S.slots_per_view * nviews;
+    const unsigned cus = A.persistent_waves / 16u;
+    const unsigned s_blocks_max = cus * 8u;  // 256-thread blocks, grid-stride
+    const unsigned s_blocks = (unsigned)std::min<unsigned long long>((slots + 255ull) / 256ull, s_blocks_max);
+    const unsigned t_waves = (unsigned)std::min<unsigned long long>((slots + 63ull) / 64ull, (unsigned long long)cus * 4ull * VXRT_TS_OCC);
+    if (s_blocks == 0)
+        return hipSuccess;
+    const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
+    hipLaunchKernelGGL(k_ts_gen, dim3(s_blocks), dim3(256), 0, stream, A, S);
+    for (int g = 0; g < gens; ++g) {
+        TsTraceArgs B;
+        B.W = A.W;
+        B.rays = S.rays[g & 1];
+        B.res = S.res;
+        B.res_voxel = g == 0 ? S.res_voxel : nullptr;
+        B.count = &S.counts[g];
+        B.ticket = &S.tickets[g];
+        B.stats = A.stats;
+        if (stats)
+            hipLaunchKernelGGL(k_ts_trace<true>, dim3(t_waves), dim3(64), 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_ts_trace<false>, dim3(t_waves), dim3(64), 0, stream, B);
+        if (second_bounce)
+            hipLaunchKernelGGL(k_ts_shade<true>, dim3(s_blocks), dim3(256), 0, stream, A, S, g);
+        else
+            hipLaunchKernelGGL(k_ts_shade<false>, dim3(s_blocks), dim3(256), 0, stream, A, S, g);
+    }
+    return hipGetLastError();
+}
 
 // The kernel a render launch runs: variant 0 = wave state machine, one lane per pixel; 1 = straightforward per-lane loops
 // (A/B and cross-check); 2 = persistent waves pulling pixels from a tile queue (k_render_persist); 3 = the same with the
@@ -582,10 +640,16 @@ int resolve_render_variant(const RenderArgs& A, int variant)
     }
     if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))
         variant = 2;  // the pool kernel packs the sample counter and the launch column into its slot words
+    if (variant == 6) {  // the wavefront pipeline indexes pixels and queue slots with 32 bits and keeps a queue per generation
+        const unsigned long long nv = A.nviews ? A.nviews : 1u;
+        const unsigned long long slots = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * 64ull * nv;
+        if (slots >= (1ull << 31) || ts_generations(A) > (int)kTsMaxGenerations || A.bounce_samples >= (1 << 24))
+            variant = 5;
+    }
     return variant;
 }
 
-hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
+hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream, const TsArgs* ts)
 {
     // one wave per workgroup: no wave waits for a slower sibling before its slot is reused (+5 % measured)
     static const int threads = getenv("VXRT_BLOCK") ? atoi(getenv("VXRT_BLOCK")) : 64;
@@ -596,6 +660,11 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
         return hipSuccess;
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
     variant = resolve_render_variant(A, variant);
+    if (variant == 6) {
+        if (ts)
+            return launch_render_ts(A, *ts, stats, stream);
+        variant = 5;  // (no workspace was leased: cannot happen through vxrt_api.hip)
+    }
     if (variant == 2 || variant == 3 || variant == 5) {
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);

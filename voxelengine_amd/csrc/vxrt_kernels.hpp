@@ -99,4 +99,20 @@ struct BatchArgs {
     int max_steps;            // Raytrace's maxSteps (VolumeRaytracer.cu:354,386); kMaxSteps unless the caller lowered it
 };
 
+constexpr unsigned kTsMaxGenerations = 64;  // primary + shadow + bounce_samples * bounce_depth must fit (else the fused kernel runs)
+constexpr uint32_t kTsNoRay = 0xFFFFFFFFu;
+
+// the HBM workspace of one launch (carved from a per-context ring slot, vxrt_api.hip)
+struct TsArgs {
+    uint4* rays[2];           // prepared ray records, 4 x uint4 per ray: generation g reads rays[g & 1], S writes the next one's
+    uint32_t* pix[2];         // the pixel (view * pixels_per_view + launch row * width + launch column) of each ray
+    uint4* res;               // one result per ray of the generation being traced: {hit | normal code << 1 | steps << 4, position}
+    long long* res_voxel;     // primary generation, when some view has a hit-index AOV: the hit voxel index per ray; or NULL
+    uint4* pstate;            // 2 x uint4 per pixel: {primary hit position, stage | primary normal code << 3 | sample << 6}, {colour, occlusion sum}
+    unsigned int* counts;     // [g] = rays of generation g (S adds, T and the next S read); zeroed per launch
+    unsigned int* tickets;    // [g] = next 64-ray ticket of generation g's queue; zeroed per launch
+    uint32_t pixels_per_view;  // width * launch_rows
+    uint32_t slots_per_view;   // 64 * tiles of the launch grid (k_ts_gen's index space)
+};
+
 }  // namespace vxrt

@@ -233,6 +233,55 @@ struct WaveTracer {
         st = ST_WALK;
     }
 
+    // The same start from a PREPARED ray (prepare_ray below, evaluated by the shading kernels of vxrt_ts.hpp at full lane
+    // occupancy): Raytrace's prologue and the first walk's three quotients arrive as 13 words, so starting a ray costs
+    // this kernel no division, no square root and no world-entry test.  LDS_COLD builds only.
+    //   a = {d.x, d.y, d.z, iv.x}  b = {iv.y, iv.z, start.x, start.y}  c = {start.z, tMax.x, tMax.y, tMax.z}
+    //   codes = entry normal code | maxSteps << 7 (the CF_RAY_CODES word)
+    __device__ __forceinline__ void begin_prepared(const WorldView& W, const uint4 a, const uint4 b, const uint4 c, const uint32_t codes)
+    {
+        static_assert(LDS_COLD, "prepared rays start LDS_COLD tracers");
+        d = mk3(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+        ivx = __uint_as_float(a.w);
+        ivy = __uint_as_float(b.x);
+        ivz = __uint_as_float(b.y);
+        up_x = d.x > 0 ? 1 : 0;
+        up_y = d.y > 0 ? 1 : 0;
+        up_z = d.z > 0 ? 1 : 0;
+        const f3 s0 = mk3(__uint_as_float(b.z), __uint_as_float(b.w), __uint_as_float(c.x));
+        cold[CF_RAY_CODES * 64] = codes;
+        cold[CF_START_X * 64] = b.z;
+        cold[CF_START_Y * 64] = b.w;
+        cold[CF_START_Z * 64] = c.x;
+        cold[CF_LAST_CI * 64] = 0xFFFFFFFFu;
+        cold[CF_TOTAL * 64] = 0u;
+        bits = W.coarse_bits;
+        // begin_walk(W, s0, 0) with its quotients from the record
+        fine = 0u;
+        ws = s0;
+        cell_x = f2i(s0.x);
+        cell_y = f2i(s0.y);
+        cell_z = f2i(s0.z);
+        tn_x = __uint_as_float(c.y);
+        tn_y = __uint_as_float(c.z);
+        tn_z = __uint_as_float(c.w);
+        point = s0;
+        steps = 0;
+        wf = 0u;
+        w_code = 0u;
+        skip = 0u;
+        const bool edge = cell_x == W.cx || cell_y == W.cy || cell_z == W.cz;  // :216-232
+        lim_x = W.cx + ((edge && d.x < 0) ? 1 : 0);
+        lim_y = W.cy + ((edge && d.y < 0) ? 1 : 0);
+        lim_z = W.cz + ((edge && d.z < 0) ? 1 : 0);
+        dm1_x = W.cx - 1;
+        dm1_y = W.cy - 1;
+        dm1_z = W.cz - 1;
+        row = W.c_row;
+        slice = W.c_slice;
+        st = ST_WALK;
+    }
+
     // parked phase: end of a walk (:395-511); call for lanes with st == ST_END
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
@@ -609,14 +658,66 @@ struct WaveTracer {
     }
 };
 
+// Raytrace's prologue (:359-384) and the first walk's set-up (:199-213) of one ray as a 13-word record -- what
+// WaveTracer::begin_ray + begin_walk compute, expression for expression (same operands, same operations, same order), so
+// that WaveTracer::begin_prepared continues exactly where they would.  Runs in the shading kernels (vxrt_ts.hpp), all
+// lanes busy, instead of in the traversal kernel's refill phase.
+struct PreparedRay {
+    uint4 a, b, c;
+    uint32_t codes;
+};
+__device__ __forceinline__ PreparedRay prepare_ray(const WorldView& W, const f3 origin, const f3 ray, const int max_steps)
+{
+    const f3 d = unit3(ray);
+    const float ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // :127-129
+    const float ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
+    const float ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
+    const int up_x = d.x > 0 ? 1 : 0, up_y = d.y > 0 ? 1 : 0, up_z = d.z > 0 ? 1 : 0;
+    f3 s0 = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
+    uint32_t ec = 0u;
+    if (!(s0.x >= 0 && s0.y >= 0 && s0.z >= 0 && s0.x < (float)W.cx && s0.y < (float)W.cy && s0.z < (float)W.cz)) {
+        // the slab test of WaveTracer::slab against the world box [1e-6, dims - 1e-6]
+        const float e = (float)1e-6;
+        const float ax = (e - s0.x) * ivx, bx = (W.wmax_x - s0.x) * ivx;
+        const float ay = (e - s0.y) * ivy, by = (W.wmax_y - s0.y) * ivy;
+        const float az = (e - s0.z) * ivz, bz = (W.wmax_z - s0.z) * ivz;
+        const float nx = lo(ax, bx), fx = hi(ax, bx);
+        const float ny = lo(ay, by), fy = hi(ay, by);
+        const float nz = lo(az, bz), fz = hi(az, bz);
+        const float t_in = hi(hi(nx, ny), nz);
+        const float t_out = lo(lo(fx, fy), fz);
+        if (!(t_out < hi(t_in, 0.0f))) {
+            s0 = mk3(s0.x + t_in * d.x, s0.y + t_in * d.y, s0.z + t_in * d.z);
+            ec = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u)) : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
+        }
+    }
+    const int cell_x = f2i(s0.x), cell_y = f2i(s0.y), cell_z = f2i(s0.z);
+    const float tn_x = d.x != 0 ? ((float)(cell_x + up_x) - s0.x) / d.x : kInf;
+    const float tn_y = d.y != 0 ? ((float)(cell_y + up_y) - s0.y) / d.y : kInf;
+    const float tn_z = d.z != 0 ? ((float)(cell_z + up_z) - s0.z) / d.z : kInf;
+    PreparedRay r;
+    r.a = make_uint4(__float_as_uint(d.x), __float_as_uint(d.y), __float_as_uint(d.z), __float_as_uint(ivx));
+    r.b = make_uint4(__float_as_uint(ivy), __float_as_uint(ivz), __float_as_uint(s0.x), __float_as_uint(s0.y));
+    r.c = make_uint4(__float_as_uint(s0.z), __float_as_uint(tn_x), __float_as_uint(tn_y), __float_as_uint(tn_z));
+    r.codes = ec | ((uint32_t)max_steps << 7);
+    return r;
+}
+
 // one ray per lane, entered by the whole wave at a converged point
 template <bool STATS, bool MASKED_LOAD = false, bool LDS_COLD = false>
 __device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
-                           TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr, uint32_t* cold_column = nullptr)
+                           TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr, uint32_t* cold_column = nullptr,
+                           const bool prepared = false)
 {
     WaveTracer<STATS, MASKED_LOAD, LDS_COLD> T;
     T.init(W, cold_column);
-    if (active)
+    if constexpr (LDS_COLD) {
+        if (active && prepared) {  // the start the traversal kernel of vxrt_ts.hpp makes (host check, tests)
+            const PreparedRay R = prepare_ray(W, origin, ray, max_steps);
+            T.begin_prepared(W, R.a, R.b, R.c, R.codes);
+        }
+    }
+    if (active && !(LDS_COLD && prepared))
         T.begin_ray(W, origin, ray, max_steps);
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);

@@ -293,7 +293,8 @@ class Context:
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
         self.kernel_variant = int(variant)
 
-    KERNEL_NAMES = {0: "k_render_wave", 1: "k_render", 2: "k_render_persist", 3: "k_render_pool", 5: "k_render_persist_lds"}
+    KERNEL_NAMES = {0: "k_render_wave", 1: "k_render", 2: "k_render_persist", 3: "k_render_pool", 5: "k_render_persist_lds",
+                    6: "k_ts_trace"}
 
     def kernel_for_launch(self, width: int, height: int, opts: "RenderOptions | None" = None, nviews: int = 0) -> int:
         """The kernel (0, 1, 2, 3 or 5) a RenderScreen (nviews = 0) or RenderViews launch of this shape runs under the
