@@ -57,7 +57,7 @@ for name, kw in MODES:
             run = (lambda: ctx.RenderViews(W, H, views, o)) if nv > 1 else (
                 lambda: ctx.RenderScreen(W, H, fbs[0], views[0]["origin"], views[0]["fwd"], views[0]["up"], views[0]["right"],
                                          vx.RenderOptions(frame_number=1, **kw), hit_aov=hits[0]))
-            for _ in range(2):
+            for _ in range(4):  # (variant 6 takes its workspace from a ring of three: every entry sized before the timed runs)
                 run()
             torch.cuda.synchronize()
             ctx.frame_stats()
@@ -86,7 +86,8 @@ for name, kw in MODES:
                 g = [int(v) for v in s2.dbg]
                 it = max(g[0], 1)
                 print("     diag: wave-iterations %.3e  walking lanes/iter %.1f | per 100 iter: end %.1f (%.1f lanes)  box %.1f (%.1f lanes)  "
-                      "next %.1f (%.1f lanes) | probes %d/%d/%d" % (g[0], g[1] / it, 100.0 * g[2] / it, g[5] / max(g[2], 1), 100.0 * g[3] / it,
+                      "next %.1f (%.1f lanes) | time share: ray-finished %.1f %%  box+end (first vote) %.1f %% | probes %d/%d/%d" % (g[0], g[1] / it, 100.0 * g[2] / it, g[5] / max(g[2], 1), 100.0 * g[3] / it,
                                                                    g[6] / max(g[3], 1), 100.0 * g[4] / it, g[7] / max(g[4], 1),
+                                                                   100.0 * g[10] / max(g[8], 1), 100.0 * g[11] / max(g[8], 1),
                                                                    s2.coarse_probes, s2.brick_entries, s2.fine_probes), flush=True)
 ctx.set_kernel_variant(4)

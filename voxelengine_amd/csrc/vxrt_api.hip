@@ -214,12 +214,12 @@ static int ts_lease(vxrt_ctx* c, const RenderArgs& A, hipStream_t stream, TsArgs
     const unsigned long long nv = A.nviews ? A.nviews : 1u;
     const unsigned long long tiles = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u);
     const unsigned long long slots = tiles * 64ull * nv;          // queue capacity: no generation has more rays than pixels
-    const unsigned long long pixels = (unsigned long long)A.width * A.launch_rows * nv;
     auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
-    const unsigned long long b_rays = up(slots * 64ull), b_pix = up(slots * 4ull), b_res = up(slots * 16ull),
-                             b_vox = A.want_hit_aov ? up(slots * 8ull) : 0ull, b_state = up(pixels * 32ull),
-                             b_cnt = up(2ull * (kTsMaxGenerations + 1u) * sizeof(unsigned int));
-    const unsigned long long need = 2 * b_rays + 2 * b_pix + b_res + b_vox + b_state + b_cnt;
+    const unsigned long long groups = tiles * nv;
+    const unsigned long long b_rays = up(slots * 64ull), b_idx = up(slots), b_gcnt = up(groups * 4ull), b_res = up(slots * 16ull),
+                             b_vox = A.want_hit_aov ? up(slots * 8ull) : 0ull, b_state = up(slots * 32ull),
+                             b_tick = up((unsigned long long)(kTsMaxGenerations + 1u) * kTsShards * 64u * sizeof(unsigned int));
+    const unsigned long long need = 2 * b_rays + 2 * b_idx + 2 * b_gcnt + b_res + b_vox + b_state + b_tick;
     slot_index = c->ts_seq.fetch_add(1u) % 3u;
     vxrt_ctx::TsSlot& T = c->ts_ring[slot_index];
     hipError_t e = ring_acquire(T.busy, stream, capturing);
@@ -241,15 +241,16 @@ static int ts_lease(vxrt_ctx* c, const RenderArgs& A, hipStream_t stream, TsArgs
     auto take = [&](unsigned long long b) { unsigned char* r = at; at += b; return r; };
     S.rays[0] = reinterpret_cast<uint4*>(take(b_rays));
     S.rays[1] = reinterpret_cast<uint4*>(take(b_rays));
-    S.pix[0] = reinterpret_cast<uint32_t*>(take(b_pix));
-    S.pix[1] = reinterpret_cast<uint32_t*>(take(b_pix));
+    S.idx[0] = reinterpret_cast<uint8_t*>(take(b_idx));
+    S.idx[1] = reinterpret_cast<uint8_t*>(take(b_idx));
+    S.gcount[0] = reinterpret_cast<uint32_t*>(take(b_gcnt));
+    S.gcount[1] = reinterpret_cast<uint32_t*>(take(b_gcnt));
     S.res = reinterpret_cast<uint4*>(take(b_res));
     S.res_voxel = b_vox ? reinterpret_cast<long long*>(take(b_vox)) : nullptr;
     S.pstate = reinterpret_cast<uint4*>(take(b_state));
-    S.counts = reinterpret_cast<unsigned int*>(take(b_cnt));
-    S.tickets = S.counts + (kTsMaxGenerations + 1u);
-    S.pixels_per_view = A.width * A.launch_rows;
+    S.tickets = reinterpret_cast<unsigned int*>(take(b_tick));
     S.slots_per_view = (uint32_t)(tiles * 64ull);
+    S.groups = (uint32_t)groups;
     return VXRT_OK;
 }
 

@@ -584,31 +584,36 @@ int ts_generations(const RenderArgs& A)
 }
 
 // Variant 6: the wavefront pipeline of vxrt_ts.hpp.  One stream, kernels in generation order:
-//   gen | T(0) S(0) | T(1) S(1) | ... ; the queue lengths stay on the device (T and S read counts[g]), no host round trip.
+//   gen | T(0) S(0) | T(1) S(1) | ... ; queue lengths stay on the device (group ray counts), no host round trip.
+// (Measured and removed: cutting the groups into 2-32 parts run as independent chains on 2-4 forked streams, so that one
+// chain's T would fill the other's low-occupancy tail and the bandwidth-bound S kernels would run beside a T.  Chains that
+// do the same work stay in lockstep -- every T is a persistent grid of the whole chip, so two of them split the wave slots
+// instead of following each other -- and more, smaller launches pay more ramps and tails than they hide: 1 / 2 / 4 streams
+// x 1 / 4 / 16 parts = 14.7 / 15.0 / 19.0 ms per 16-view step, 16 parts on one stream 31.9; profiles/r03_ts_pipeline.md.)
 hipError_t launch_render_ts(const RenderArgs& A, const TsArgs& S, bool stats, hipStream_t stream)
 {
+    static_assert(kTsShards == VXRT_TS_SHARDS, "queue shards");
     const int gens = ts_generations(A);
-    hipError_t e = hipMemsetAsync(S.counts, 0, 2u * (kTsMaxGenerations + 1u) * sizeof(unsigned int), stream);  // counts + tickets
+    if (S.groups == 0)
+        return hipSuccess;
+    hipError_t e = hipMemsetAsync(S.tickets, 0, (size_t)gens * kTsShards * 64u * sizeof(unsigned int), stream);
     if (e != hipSuccess)
         return e;
-    const unsigned nviews = A.nviews ? A.nviews : 1u;
-    const unsigned long long slots = (unsigned long long)S.slots_per_view * nviews;
     const unsigned cus = A.persistent_waves / 16u;
-    const unsigned s_blocks_max = cus * 8u;  // 256-thread blocks, grid-stride
-    const unsigned s_blocks = (unsigned)std::min<unsigned long long>((slots + 255ull) / 256ull, s_blocks_max);
-    const unsigned t_waves = (unsigned)std::min<unsigned long long>((slots + 63ull) / 64ull, (unsigned long long)cus * 4ull * VXRT_TS_OCC);
-    if (s_blocks == 0)
-        return hipSuccess;
     const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
+    // S: one wave per group, 4 waves per block, at most 8 resident blocks' worth per CU (the loops stride over the groups)
+    const unsigned s_blocks = (unsigned)std::min<unsigned long long>(((unsigned long long)S.groups + 3ull) / 4ull, (unsigned long long)cus * 8ull);
+    const unsigned t_waves = (unsigned)std::min<unsigned long long>((unsigned long long)S.groups, (unsigned long long)cus * 4ull * VXRT_TS_OCC);
     hipLaunchKernelGGL(k_ts_gen, dim3(s_blocks), dim3(256), 0, stream, A, S);
     for (int g = 0; g < gens; ++g) {
         TsTraceArgs B;
         B.W = A.W;
         B.rays = S.rays[g & 1];
+        B.gcount = S.gcount[g & 1];
         B.res = S.res;
         B.res_voxel = g == 0 ? S.res_voxel : nullptr;
-        B.count = &S.counts[g];
-        B.ticket = &S.tickets[g];
+        B.ticket = S.tickets + (size_t)g * kTsShards * 64u;
+        B.groups = S.groups;
         B.stats = A.stats;
         if (stats)
             hipLaunchKernelGGL(k_ts_trace<true>, dim3(t_waves), dim3(64), 0, stream, B);

@@ -99,20 +99,26 @@ struct BatchArgs {
     int max_steps;            // Raytrace's maxSteps (VolumeRaytracer.cu:354,386); kMaxSteps unless the caller lowered it
 };
 
+constexpr unsigned kTsShards = 16;  // counters per queue (VXRT_TS_SHARDS, vxrt_ts.hpp)
 constexpr unsigned kTsMaxGenerations = 64;  // primary + shadow + bounce_samples * bounce_depth must fit (else the fused kernel runs)
 constexpr uint32_t kTsNoRay = 0xFFFFFFFFu;
 
-// the HBM workspace of one launch (carved from a per-context ring slot, vxrt_api.hip)
+// The HBM workspace of one launch (carved from a per-context ring slot, vxrt_api.hip).  Everything is keyed by PIXEL SLOT:
+// slot = view * slots_per_view + tile * 64 + pixel of the 8x8 tile, tiles in the launch's hand-out order.  A GROUP is the
+// 64 slots of one tile; a generation's rays are compacted INSIDE their group (a wave of S writes the rays of its group
+// back to back at the group's base and the group's ray count: ballots only, no global atomic), so all arrays are read and
+// written with whole-wave contiguous accesses and the traversal kernel's queue is "the groups in order".
 struct TsArgs {
-    uint4* rays[2];           // prepared ray records, 4 x uint4 per ray: generation g reads rays[g & 1], S writes the next one's
-    uint32_t* pix[2];         // the pixel (view * pixels_per_view + launch row * width + launch column) of each ray
-    uint4* res;               // one result per ray of the generation being traced: {hit | normal code << 1 | steps << 4, position}
+    uint4* rays[2];           // prepared ray records, 4 x uint4 per slot: generation g reads rays[g & 1], S writes the next one's
+    uint8_t* idx[2];          // per ray (group base + rank): the pixel of the ray, as its index in the group (0..63)
+    uint32_t* gcount[2];      // per group: rays of the generation in that group
+    uint4* res;               // one result per ray (group base + rank): {hit | normal code << 1 | steps << 4, position}
     long long* res_voxel;     // primary generation, when some view has a hit-index AOV: the hit voxel index per ray; or NULL
-    uint4* pstate;            // 2 x uint4 per pixel: {primary hit position, stage | primary normal code << 3 | sample << 6}, {colour, occlusion sum}
-    unsigned int* counts;     // [g] = rays of generation g (S adds, T and the next S read); zeroed per launch
-    unsigned int* tickets;    // [g] = next 64-ray ticket of generation g's queue; zeroed per launch
-    uint32_t pixels_per_view;  // width * launch_rows
-    uint32_t slots_per_view;   // 64 * tiles of the launch grid (k_ts_gen's index space)
+    uint4* pstate;            // 2 x uint4 per pixel slot: {primary hit position, stage | primary normal code << 3 | sample << 6}, {colour, occlusion sum}
+    unsigned int* tickets;    // generation g's queue heads: kTsShards counters, 64 words apart (a cache line each), from
+                              // tickets[g * kTsShards * 64]; zeroed per launch
+    uint32_t slots_per_view;  // 64 * tiles of the launch grid
+    uint32_t groups;          // slots_per_view / 64 * views
 };
 
 }  // namespace vxrt
