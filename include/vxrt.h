@@ -50,12 +50,20 @@ int vxrt_synchronize(vxrt_ctx *ctx);
  *       and for a large single-view launch (at least 4 M rays, counting one shadow and one bounce ray per pixel where
  *       enabled), 2 for a small one;
  *   2 = persistent waves, one pixel chain per lane, pixels from a tile queue;
- *   3 = the same with the pixel chains pooled in LDS;
  *   5 = 2 with the state only the parked phases touch in LDS: 96 VGPRs, 5 waves per SIMD;
- *   0 = wave-level state machine with one lane per pixel; 1 = straightforward per-lane loops.
- * The non-default ones exist for A/B timing and as on-device cross-checks.  (Batch traces: 1 = straightforward,
+ *   6 = wavefront pipeline: a traversal kernel and a shading kernel that hand each other prepared ray records through HBM,
+ *       generation by generation (primary, shadow, bounce): measured within 3 % of 5 on 16-view launches, slower on one view;
+ *   1 = straightforward per-lane loops (the on-device cross-check).
+ * Variants 0 (wave-level state machine, one lane per pixel) and 3 (pixel chains pooled in LDS) are A/B kernels of the
+ * experiments build (libvxrt_exp.so) and are refused by the product library.  (Batch traces: 1 = straightforward,
  * 0 = the wave-level tracer, anything else = the wave-level tracer behind a persistent ray queue.) */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
+/* 1 when the library was built with -DVXRT_EXPERIMENTS (variants 0 and 3, development knobs read from the environment) */
+int vxrt_has_experiments(void);
+/* Size of the persistent kernels' grid, in wavefronts per compute unit at 4 waves per SIMD (default 16 = 4 per SIMD; the
+ * 5- and 6-wave kernels scale it).  For tests that need a small grid (a batch then takes the queue kernel at a few
+ * thousand rays) and for occupancy measurements; 0 restores the default. */
+int vxrt_set_persistent_waves_per_cu(vxrt_ctx *ctx, int waves_per_cu);
 
 /* ---- world upload.  Replaces VoxelRaytracer3D::UploadVoxelBuffer,
  * ::UploadVoxelBufferDatas, ::UploadVoxelBufferDataBounds and ::SetFactor

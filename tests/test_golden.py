@@ -89,7 +89,7 @@ def test_hip_reproduces_golden_frames(eng, vxo, name):
     opts = vx.RenderOptions(mode=kw.get("mode", 0), checkerboard=bool(kw.get("checkerboard", 0)), shadow=bool(kw.get("shadow", 0)),
                             bounce_samples=kw.get("bounce_samples", 0), bounce_all_hits=bool(kw.get("bounce_all_hits", 0)),
                             bounce_depth=kw.get("bounce_depth", 1), frame_number=kw["frame_number"])
-    for variant in (2, 0, 1):
+    for variant in (2, 5, 6, 1):
         ctx.set_kernel_variant(variant)
         ctx.frame_stats()
         fb = torch.from_numpy(stale.copy()).cuda()

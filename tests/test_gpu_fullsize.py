@@ -113,7 +113,7 @@ def test_idempotence_variants_and_strip_shards(big):
     assert torch.equal(a, b)
     default = ctx.kernel_variant
     try:
-        for variant in (0, 1, 2, 3, 5, 6):  # three separately written kernels, one frame
+        for variant in (1, 2, 5, 6):  # three separately written kernels, one frame
             ctx.set_kernel_variant(variant)
             b.zero_()
             ctx.RenderScreen(W, H, b, pos, fwd, up, right, vx.RenderOptions(**base))

@@ -60,11 +60,8 @@ def test_trace_batch_persistent_queue(eng, vxo, n):
     with one persistent wave per CU so that these batch sizes are over the threshold."""
     import os
     vx, _, _ = eng
-    os.environ["VXRT_WAVES_PER_CU"] = "1"
-    try:
-        ctx = vx.Context(0)
-    finally:
-        del os.environ["VXRT_WAVES_PER_CU"]
+    ctx = vx.Context(0)
+    ctx.set_persistent_waves_per_cu(1)   # a small persistent grid: batches of this size take the queue kernel
     try:
         w = helpers.random_voxel_world(vxo, (128, 128, 128), 16, 0.004, 21)
         _upload(ctx, w)
@@ -89,11 +86,8 @@ def test_invalid_rays_are_defined_misses_and_a_bad_camera_is_rejected(eng, vxo):
     the persistent queue.  A camera with a non-finite component is an error, not a frame."""
     import os
     vx, ctx0, torch = eng
-    os.environ["VXRT_WAVES_PER_CU"] = "1"   # small persistent grid: the 300 000-ray batch below takes the queue kernel
-    try:
-        ctx = vx.Context(0)
-    finally:
-        del os.environ["VXRT_WAVES_PER_CU"]
+    ctx = vx.Context(0)
+    ctx.set_persistent_waves_per_cu(1)   # a small persistent grid: batches of this size take the queue kernel
     try:
         w = helpers.random_voxel_world(vxo, (128, 128, 128), 16, 0.004, 33)
         _upload(ctx, w)
@@ -113,8 +107,9 @@ def test_invalid_rays_are_defined_misses_and_a_bad_camera_is_rejected(eng, vxo):
             bad[idx] = True
         good = ~bad
         cpu = w.trace_batch(o[good], d[good])
-        for variant in (2, 0, 1):
+        for variant, waves_per_cu in ((2, 1), (2, 0), (1, 0)):   # the queue kernel, one ray per lane, straightforward
             ctx.set_kernel_variant(variant)
+            ctx.set_persistent_waves_per_cu(waves_per_cu)
             g = ctx.Raytrace(o, d, want_stats=True)
             assert g["stats"].primary_rays == n
             sub = {k: g[k][good] for k in ("hit", "steps", "voxel", "hitPoint", "normal")}
@@ -148,10 +143,11 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6])
 def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
-    """Variants: 0 wave state machine (one lane per pixel), 1 straightforward per-lane loops, 2 persistent waves
-    with a pixel queue.  All give the oracle's bits, in every render mode."""
+    """Variants: 1 straightforward per-lane loops, 2 persistent waves with a pixel queue, 5 the same with its cold state
+    in LDS, 6 the traversal / shading pipeline over ray queues.  All give the oracle's bits, in every render mode.
+    (Batch traces: 1 straightforward, anything else the wave-level tracer.)"""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
@@ -204,7 +200,7 @@ def test_quirk_cases_on_gpu(eng, vxo):
             _upload(ctx, w)
             e = case["expect"]
             ctx.set_batch_max_steps(case["max_steps"])
-            for variant in (2, 0, 1, 3):
+            for variant in (2, 1):   # (a one-ray batch: 2 = the wave-level tracer, 1 = the straightforward loops)
                 ctx.set_kernel_variant(variant)
                 r = ctx.Raytrace([o], [d], want_stats=True)
                 assert bool(r["hit"][0]) == e["hit"] and int(r["steps"][0]) == e["steps"], (name, variant)
@@ -226,11 +222,8 @@ def test_batch_max_steps_matches_the_oracle(eng, vxo):
     vx, ctx, _ = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     o, d = helpers.mixed_rays(w.dims, 40000, 33)
-    os.environ["VXRT_WAVES_PER_CU"] = "1"   # a second context whose persistent batch kernel takes batches this small
-    try:
-        small = vx.Context(0)
-    finally:
-        del os.environ["VXRT_WAVES_PER_CU"]
+    small = vx.Context(0)
+    small.set_persistent_waves_per_cu(1)   # a small persistent grid: batches of this size take the queue kernel
     try:
         for c in (ctx, small):
             _upload(c, w)
@@ -477,7 +470,7 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("variant", [2, 3, 4, 5, 6, 0])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6, 1])
 def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
     """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).
     Every view must be byte for byte the frame RenderScreen produces for it -- frame, hit-index AOV and colour AOV --
@@ -633,7 +626,7 @@ def test_errors_are_reported_not_swallowed(eng, vxo):
 
 def test_kernel_for_launch_reports_the_policy(eng, vxo):
     """vxrt_kernel_for_launch: what the default (variant 4) resolves to per launch shape, and that a forced variant is
-    reported as itself (the pool kernel falls back to the pixel-per-lane kernel beyond its packed sample counter)."""
+    reported as itself."""
     vx, ctx, torch = eng
     default = ctx.kernel_variant
     try:
@@ -646,11 +639,20 @@ def test_kernel_for_launch_reports_the_policy(eng, vxo):
         assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions(shadow=True, checkerboard=True)) == 2  # half the rows
         assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions(shadow=True, strip_rows=16, strip_count=8, strip_index=3,
                                                                   compact=True)) == 2   # a 1/8 shard of a 4K frame
-        for v in (0, 1, 2, 3, 5):
+        for v in (1, 2, 5, 6):
             ctx.set_kernel_variant(v)
             assert ctx.kernel_for_launch(640, 480, shaded) == v
-        ctx.set_kernel_variant(3)
-        assert ctx.kernel_for_launch(640, 480, vx.RenderOptions(bounce_samples=2000)) == 2
-        assert ctx.KERNEL_NAMES[5] == "k_render_persist_lds"
+        # the wavefront pipeline keeps one queue per ray generation: beyond 64 generations the fused kernel runs
+        ctx.set_kernel_variant(6)
+        assert ctx.kernel_for_launch(640, 480, vx.RenderOptions(shadow=True, bounce_samples=100)) == 5
+        assert ctx.KERNEL_NAMES[5] == "k_render_persist_lds" and ctx.KERNEL_NAMES[6] == "k_ts_trace"
+        # variants 0 and 3 are A/B kernels of the experiments build (libvxrt_exp.so): the product library refuses them
+        for v in (0, 3):
+            if ctx.has_experiments():
+                ctx.set_kernel_variant(v)
+                assert ctx.kernel_for_launch(640, 480, shaded) == v
+            else:
+                with pytest.raises(vx.VxrtError):
+                    ctx.set_kernel_variant(v)
     finally:
         ctx.set_kernel_variant(default)

@@ -74,7 +74,7 @@ while time.time() < t_end:
     opts = vx.RenderOptions(mode=kw["mode"], checkerboard=bool(kw["checkerboard"]), shadow=bool(kw["shadow"]),
                             bounce_samples=kw["bounce_samples"], bounce_all_hits=bool(kw["bounce_all_hits"]),
                             bounce_depth=kw["bounce_depth"], ortho=bool(kw["ortho"]), frame_number=kw["frame_number"])
-    for variant in (2, 3, 5, 0, 1):
+    for variant in ((2, 3, 5, 6, 0, 1) if ctx.has_experiments() else (2, 5, 6, 1)):   # 0 and 3: the experiments build (VXRT_LIB=.../libvxrt_exp.so)
         ctx.set_kernel_variant(variant)
         d_fb = torch.from_numpy(fb0.copy()).cuda()
         d_hit = torch.full((H, W), -1, dtype=torch.int64, device="cuda")
@@ -85,7 +85,7 @@ while time.time() < t_end:
             fail("hit indices variant %d" % variant, seed, "cam %s %dx%d %r" % (cam, W, H, kw))
     # the same configuration as a multi-view launch: this view plus two others, each against its own oracle frame;
     # alternately through the pixel-per-lane kernel and the LDS pool kernel
-    ctx.set_kernel_variant((2, 3, 5)[seed % 3])
+    ctx.set_kernel_variant((2, 6, 5)[seed % 3])
     views, wants = [], []
     for j in range(3):
         cj = cam if j == 0 else str(rng.choice(["A", "B", "C", "D"]))
@@ -107,5 +107,5 @@ while time.time() < t_end:
         print("round %d (seed %d): %d rays, %d frames checked, all equal" % (rounds, seed, rays_checked, frames_checked), flush=True)
     seed += 1
 
-print("FUZZ OK: %d rounds, %d batch rays (2 kernel variants), %d frames (5 kernel variants + multi-view launches), 0 mismatches, seeds %s..%d" % (
+print("FUZZ OK: %d rounds, %d batch rays (2 kernel variants), %d frames (every render kernel of the loaded library + multi-view launches), 0 mismatches, seeds %s..%d" % (
     rounds, rays_checked, frames_checked, sys.argv[2] if len(sys.argv) > 2 else "1000", seed - 1), flush=True)

@@ -2,6 +2,7 @@
 # usage: tools/ab_configs.sh <out-tag> <variant> ...   (on the GPU box via gpurun)
 # the BASELINE configurations other than bench.py's default, each with the given render kernel variants (VXRT_VARIANT)
 set -o pipefail
+# VXRT_VARIANT / VXRT_WAVES_PER_CU are read by the EXPERIMENTS build only: make -C voxelengine_amd/csrc libvxrt_exp.so first
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/abc_$1; shift
 mkdir -p $OUT

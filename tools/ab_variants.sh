@@ -3,12 +3,13 @@
 # A/B of render kernel variants (VXRT_VARIANT) and library builds on the bench workload in ONE GPU session, the default
 # first and last.
 set -o pipefail
+# VXRT_VARIANT / VXRT_WAVES_PER_CU are read by the EXPERIMENTS build only: make -C voxelengine_amd/csrc libvxrt_exp.so first
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/abv_$1; shift
 mkdir -p $OUT
 run() {
   IFS=: read -r var tag wpc <<< "$1"
-  local lib=$R/voxelengine_amd/csrc/libvxrt.so
+  local lib=$R/voxelengine_amd/csrc/libvxrt_exp.so
   [ -n "$tag" ] && [ "$tag" != base ] && lib=$R/voxelengine_amd/csrc/libvxrt_$tag.so
   VXRT_VARIANT=$var VXRT_LIB=$lib VXRT_WAVES_PER_CU=$wpc python3 $R/bench.py --cpu-baseline off ${BENCH_ARGS:-} > $OUT/$2.json 2> $OUT/$2.err || { echo "$1 failed"; tail -20 $OUT/$2.err; echo "stopping: no further GPU run behind a failed one (full log: $OUT/$2.err)"; exit 1; }
   python3 - "$OUT/$2.json" "$1" <<'PY'

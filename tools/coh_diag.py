@@ -3,7 +3,7 @@ one 8x8 tile per wave, no refill) against persistent waves with per-lane refill 
 frames with primary rays only / + shadow / + bounce.  Prints, per launch shape: time, iterations, walking lanes per
 iteration, phase executions and the lanes they served.
 
-usage: coh_diag.py [views]
+usage: VXRT_LIB=voxelengine_amd/csrc/libvxrt_exp.so coh_diag.py [views]   (variant 0 lives in the experiments build)
 """
 import os
 import sys

@@ -65,6 +65,7 @@ struct vxrt_ctx {
     int kernel_variant = 4;          // render: 4 = persistent waves, kernel picked per launch (resolve_render_variant); 2 / 3 / 5 = one of
                                      // the two persistent kernels everywhere; 0 = wave state machine, 1 = straightforward
     unsigned persistent_waves = 4096;
+    unsigned cus = 256;
     unsigned long long* d_stats = nullptr;
     // Counters only ever grow on the device (atomics from any stream); "read and clear" is a host-side snapshot that the
     // next read subtracts, so nothing clears device memory under running kernels.
@@ -321,12 +322,15 @@ int vxrt_create(int device, vxrt_ctx** out)
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
         c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
+        c->cus = (unsigned)prop.multiProcessorCount;
+#ifdef VXRT_EXPERIMENTS  // A/B builds only (make libvxrt_exp.so): the product library reads no environment variable
         if (const char* v = getenv("VXRT_VARIANT"))                       // A/B of the render kernels (tools/)
             if (atoi(v) >= 0 && atoi(v) <= 6)
                 c->kernel_variant = atoi(v);
-        if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments only
+        if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments
             if (atoi(e) > 0 && atoi(e) <= 32)
                 c->persistent_waves = (unsigned)prop.multiProcessorCount * (unsigned)atoi(e);
+#endif
     }
     if (e != hipSuccess) {
         delete c;
@@ -377,8 +381,29 @@ int vxrt_kernel_for_launch(const vxrt_ctx* c, uint32_t width, uint32_t height, c
     return vxrt::resolve_render_variant(A, c->kernel_variant);
 }
 
+int vxrt_set_persistent_waves_per_cu(vxrt_ctx* c, int waves_per_cu)
+{
+    if (!c || waves_per_cu < 0 || waves_per_cu > 32)
+        return fail(VXRT_ERR_INVALID, "waves_per_cu must be in [1, 32], or 0 for the default");
+    c->persistent_waves = c->cus * (unsigned)(waves_per_cu == 0 ? 16 : waves_per_cu);
+    return VXRT_OK;
+}
+
+int vxrt_has_experiments(void)
+{
+#ifdef VXRT_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
+}
+
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
+#ifndef VXRT_EXPERIMENTS
+    if (c && (variant == 0 || variant == 3))
+        return fail(VXRT_ERR_INVALID, "render kernel variants 0 (wave state machine) and 3 (LDS pixel pool) are A/B kernels of the experiments build (make -C voxelengine_amd/csrc libvxrt_exp.so)");
+#endif
     if (!c || variant < 0 || variant > 6)
         return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default, picked per launch), 5 (persistent, cold state in LDS, 5 waves per SIMD) or 6 (traversal / shading kernels over ray queues)");
     c->kernel_variant = variant;
@@ -921,7 +946,12 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     B.persistent_waves = c->persistent_waves;
     B.max_steps = c->batch_max_steps;
     unsigned int* d_dbg = nullptr;
-    if (stats && getenv("VXRT_DEBUG_TRACE")) {  // development: dump the wave loop's view of ray 0
+#ifdef VXRT_EXPERIMENTS
+    const bool debug_trace = getenv("VXRT_DEBUG_TRACE") != nullptr;
+#else
+    const bool debug_trace = false;
+#endif
+    if (stats && debug_trace) {  // development: dump the wave loop's view of ray 0
         VX_HIP(hipMalloc((void**)&d_dbg, 400 * 12 * 4));
         VX_HIP(hipMemset(d_dbg, 0xFF, 400 * 12 * 4));
         B.dbg_trace = d_dbg;

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void k_deinterleave(const uint4* __restrict__ 
 // ---- wave-level kernels (vxrt_wave.hpp): every trace is entered by the whole wavefront at a converged point
 // with an `active` predicate, so the ballots inside see all 64 lanes ---------------------------------------
 
+#ifdef VXRT_EXPERIMENTS  // variant 0: A/B builds only (make libvxrt_exp.so)
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
 {
@@ -523,6 +524,8 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
     }
 }
 
+#endif  // VXRT_EXPERIMENTS
+
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 {
@@ -569,7 +572,9 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 
 #include "vxrt_persist.hpp"
 #include "vxrt_persist_lds.hpp"
-#include "vxrt_pool.hpp"
+#ifdef VXRT_EXPERIMENTS
+#include "vxrt_pool.hpp"  // variant 3: A/B builds only
+#endif
 #include "vxrt_batch_persist.hpp"
 #include "vxrt_ts.hpp"
 
@@ -643,8 +648,13 @@ int resolve_render_variant(const RenderArgs& A, int variant)
                                         (1ull + (A.shadow ? 1ull : 0ull) + (A.bounce_samples > 0 ? 1ull : 0ull));
         variant = (A.nviews >= 2 || rays >= 4000000ull) ? 5 : 2;
     }
+#ifdef VXRT_EXPERIMENTS
     if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))
         variant = 2;  // the pool kernel packs the sample counter and the launch column into its slot words
+#else
+    if (variant == 0 || variant == 3)
+        variant = 2;  // (not in this build; vxrt_set_kernel_variant refuses them)
+#endif
     if (variant == 6) {  // the wavefront pipeline indexes pixels and queue slots with 32 bits and keeps a queue per generation
         const unsigned long long nv = A.nviews ? A.nviews : 1u;
         const unsigned long long slots = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * 64ull * nv;
@@ -657,13 +667,21 @@ int resolve_render_variant(const RenderArgs& A, int variant)
 hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream, const TsArgs* ts)
 {
     // one wave per workgroup: no wave waits for a slower sibling before its slot is reused (+5 % measured)
+#ifdef VXRT_EXPERIMENTS
     static const int threads = getenv("VXRT_BLOCK") ? atoi(getenv("VXRT_BLOCK")) : 64;
+#else
+    constexpr int threads = 64;
+#endif
     const unsigned tile = threads == 64 ? 8u : 16u;
     dim3 block(threads == 64 ? 64 : 256, 1, 1);
     dim3 grid((A.width + tile - 1) / tile, (A.launch_rows + tile - 1) / tile, 1);
     if (grid.x == 0 || grid.y == 0)
         return hipSuccess;
+#ifdef VXRT_EXPERIMENTS
     static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
+#else
+    constexpr int lds = 0;
+#endif
     variant = resolve_render_variant(A, variant);
     if (variant == 6) {
         if (ts)
@@ -681,10 +699,15 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             return e;
         const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
         const dim3 g(waves), b(64);
+#ifdef VXRT_EXPERIMENTS
+#define VXRT_LAUNCH_POOL(S, B2, M) hipLaunchKernelGGL((k_render_pool<S, B2, M>), g, b, 0, stream, A)
+#else
+#define VXRT_LAUNCH_POOL(S, B2, M) (void)0
+#endif
 #define VXRT_LAUNCH_PERSIST(S, B2, M)                                                        \
     do {                                                                                     \
         if (variant == 3)                                                                    \
-            hipLaunchKernelGGL((k_render_pool<S, B2, M>), g, b, 0, stream, A);               \
+            VXRT_LAUNCH_POOL(S, B2, M);                                                      \
         else if (variant == 5)                                                               \
             hipLaunchKernelGGL((k_render_persist_lds<S, B2, M>), g, b, 0, stream, A);        \
         else                                                                                 \
@@ -702,6 +725,7 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             else VXRT_LAUNCH_PERSIST(false, false, false);
         }
 #undef VXRT_LAUNCH_PERSIST
+#undef VXRT_LAUNCH_POOL
         return hipSuccess;
     }
     if (variant == 1) {
@@ -709,12 +733,15 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             hipLaunchKernelGGL(k_render<true>, grid, block, lds, stream, A);
         else
             hipLaunchKernelGGL(k_render<false>, grid, block, lds, stream, A);
-    } else {
+    }
+#ifdef VXRT_EXPERIMENTS
+    else {
         if (stats)
             hipLaunchKernelGGL(k_render_wave<true>, grid, block, lds, stream, A);
         else
             hipLaunchKernelGGL(k_render_wave<false>, grid, block, lds, stream, A);
     }
+#endif
     return hipSuccess;
 }
 

@@ -293,6 +293,15 @@ class Context:
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
         self.kernel_variant = int(variant)
 
+    def set_persistent_waves_per_cu(self, waves_per_cu: int) -> None:
+        """Grid of the persistent kernels in wavefronts per CU at 4 waves per SIMD (0 = default 16); tests use a small
+        grid so that modest batches take the queue kernel."""
+        N.check(self._L.vxrt_set_persistent_waves_per_cu(self._h, int(waves_per_cu)))
+
+    def has_experiments(self) -> bool:
+        """True for the A/B build of the library (variants 0 and 3, knobs from the environment)."""
+        return bool(self._L.vxrt_has_experiments())
+
     KERNEL_NAMES = {0: "k_render_wave", 1: "k_render", 2: "k_render_persist", 3: "k_render_pool", 5: "k_render_persist_lds",
                     6: "k_ts_trace"}
 
