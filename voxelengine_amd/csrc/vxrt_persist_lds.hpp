@@ -33,17 +33,40 @@ enum : int { PF_STAGE = 0, PF_TX, PF_ROW, PF_POS_X, PF_POS_Y, PF_POS_Z, PF_COL_X
 #define PX_ST_POS() do { PX_ST_F(PF_POS_X, position.x); PX_ST_F(PF_POS_Y, position.y); PX_ST_F(PF_POS_Z, position.z); } while (0)
 #define PX_LD_COL() do { PX_LD_F(PF_COL_X, color.x); PX_LD_F(PF_COL_Y, color.y); PX_LD_F(PF_COL_Z, color.z); } while (0)
 #define PX_ST_COL() do { PX_ST_F(PF_COL_X, color.x); PX_ST_F(PF_COL_Y, color.y); PX_ST_F(PF_COL_Z, color.z); } while (0)
+// The launch's arguments as the ray-finished phase reads them.  The ~50 frame arguments (camera, light, mode words, strips,
+// buffers) are used by that phase only, but as kernel arguments the compiler loads them once, before the loop, and keeps
+// them in scalar registers for the kernel's lifetime -- beside the probe loop's wave masks they do not fit (74 spilled
+// SGPRs: the phase fetched them back from vector-register lanes with ~150 v_readlane + s_nop pairs per execution).  With
+// VXRT_KERNARG_RELOAD the phase reads them from the kernel-argument segment through a pointer the optimiser cannot see
+// through (an empty asm "modifies" it at every execution), so the loads stay inside the phase -- a few s_load_dwordx8/x16
+// from the scalar cache -- and the values occupy scalar registers only while the phase runs.
+// Measured (profiles/r03_kernarg_reload.md): spilled SGPRs 74 -> 0, spilled VGPRs 12 -> 7 (one view: 7 -> 0, no scratch at
+// all), v_readlane in the kernel 150 -> 8; 16 views per launch 5602 -> 5707 Mrays/s (+1.9 %), one view per launch +1.2 %.
+#ifndef VXRT_NO_KERNARG_RELOAD
+#define VXRT_KERNARG_RELOAD 1
+#endif
+__device__ __forceinline__ const RenderArgs& kernarg_reload(const RenderArgs& in_registers)
+{
+#ifdef VXRT_KERNARG_RELOAD
+    auto* p = (const __attribute__((address_space(4))) RenderArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const RenderArgs*)p;
+#else
+    return in_registers;
+#endif
+}
+
 template <bool STATS, bool BOUNCE2, bool MULTI>
-__global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds(RenderArgs A)
+__global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds(RenderArgs A_kern)
 {
     constexpr bool LDS = true;  // (the PX_* macros and the tracer's LDS_COLD parameter)
     __shared__ uint32_t cold_block[(CF_TRACER_FIELDS + PF_PIXEL_FIELDS) * 64 + 4];  // + the wave's four ray counters
-    const WorldView& W = A.W;
+    const WorldView& W = A_kern.W;
     const int lane = threadIdx.x & 63;
     uint32_t* const PX = &cold_block[CF_TRACER_FIELDS * 64 + lane];  // this lane's column of the pixel fields
     // (staging the launch's per-view parameters in LDS instead of gathering them from L2 in the ray-finished phase
     // was measured: -0.3 %, the loads are not what that phase waits for)
-    auto lane_view = [&](uint32_t v) -> LaneView {
+    auto lane_view = [&](const RenderArgs& A, uint32_t v) -> LaneView {
         if (MULTI) {
             const ViewArgs& S = A.views[v];
             return LaneView{S.origin, S.fwd, S.up, S.right, S.frame_number, S.fb, S.color_aov, S.hit_aov};
@@ -70,7 +93,6 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
         cold_block[(CF_TRACER_FIELDS + PF_PIXEL_FIELDS) * 64 + lane] = 0u;
 
     // the wave's share of the tile queue (wave-uniform)
-    const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
     // Whole tiles per ticket: one same-address atomic per 64 pixels.  A finer queue is limited by the atomic rate
     // (measured: 2x slower frames at 8 pixels per ticket), and handing out only the last tiles in smaller pieces
     // did not shorten the frame either.
@@ -84,12 +106,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
     unsigned long long px_t0 = 0;
 #endif
 
-    const f3 L = A.light_dir;
-    const f3 sray = A.light_unit;  // unit3(L), evaluated once on the host
 
     // store one finished pixel (setPixelColor + the debug overlays of screenDispatch, Renderer.cu:213-275)
     // `shaded`: the shaded colour of a hit pixel; for a miss, the camera ray's direction (kept in `color` since launch)
-    auto store_pixel = [&](const PixelCoords& pc, const LaneView& V, f3 origin, bool hit, f3 normal, f3 pos, f3 shaded) {
+    auto store_pixel = [&](const RenderArgs& A, const PixelCoords& pc, const LaneView& V, f3 origin, bool hit, f3 normal, f3 pos, f3 shaded) {
         PixelSink sink{A, pc.out_row, V.fb, V.color_aov};
         const int Wd = (int)A.width, Hd = (int)A.height;
         if (hit) {
@@ -177,6 +197,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
                 dg_lanes[0] += (unsigned)c_next;
                 dg_next_ticks -= wall_clock64();
             }
+            const RenderArgs& A = kernarg_reload(A_kern);
+            const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
+            const f3 L = A.light_dir;
+            const f3 sray = A.light_unit;  // unit3(L), evaluated once on the host
             PX_LD_U(PF_STAGE, stage);
             PX_LD_U(PF_TX, px_tx);
             PX_LD_U(PF_ROW, px_row);
@@ -185,7 +209,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
             f3 l_origin = mk3(0, 0, 0), l_dir = mk3(1, 0, 0);
             int l_max = kMaxSteps;
             if (T.st == ST_DONE && stage != PX_NONE) {
-                const LaneView V = lane_view(MULTI ? px_row >> 16 : 0u);
+                const LaneView V = lane_view(A, MULTI ? px_row >> 16 : 0u);
                 const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
                 const f3 origin = camera_origin(A, V, pc.x, pc.y);
                 TraceResult r;
@@ -300,8 +324,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
                     PX_LD_I(PF_PSTEPS, p_steps);
                     // (the view's buffer pointers are fetched here, where they are used, instead of being carried --
                     // spilled -- from the top of the phase)
-                    const LaneView Vs = lane_view(MULTI ? px_row >> 16 : 0u);
-                    store_pixel(pc, Vs, origin, stage != PX_NONE, normal, position, color);
+                    const LaneView Vs = lane_view(A, MULTI ? px_row >> 16 : 0u);
+                    store_pixel(A, pc, Vs, origin, stage != PX_NONE, normal, position, color);
 #ifdef VXRT_TAIL_DEBUG  // development: when each pixel's chain started / ended (100 MHz ticks), and its primary steps
                     if (STATS && V.color_aov) {
                         float* o = V.color_aov + ((size_t)pc.out_row * A.width + (size_t)pc.x) * 3;
@@ -360,7 +384,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
                 want = __ballot(T.st == ST_DONE && stage == PX_NONE && !got);
             }
             if (got) {
-                const LaneView V = lane_view(MULTI ? px_row >> 16 : 0u);
+                const LaneView V = lane_view(A, MULTI ? px_row >> 16 : 0u);
                 const PixelCoords pc = pixel_coords(A, V.frame_number, px_tx, MULTI ? px_row & 0xFFFFu : px_row);
                 camera_ray(A, V, pc.x, pc.y, l_origin, l_dir);
                 color = l_dir;  // the pixel's colour if the primary ray misses (Renderer.cu:254-258)
@@ -444,30 +468,30 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
         n_hits = C[3];
     }
     const unsigned long long s0 = n_primary, s1 = n_shadow, s2 = n_bounce, s3 = n_hits;
-    if (lane == 0 && A.stats) {
-        atomicAdd(&A.stats[kStatPrimary], s0);
-        atomicAdd(&A.stats[kStatShadow], s1);
-        atomicAdd(&A.stats[kStatBounce], s2);
-        atomicAdd(&A.stats[kStatPrimaryHits], s3);
+    if (lane == 0 && A_kern.stats) {
+        atomicAdd(&A_kern.stats[kStatPrimary], s0);
+        atomicAdd(&A_kern.stats[kStatShadow], s1);
+        atomicAdd(&A_kern.stats[kStatBounce], s2);
+        atomicAdd(&A_kern.stats[kStatPrimaryHits], s3);
     }
     if (STATS) {
         unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries), p2 = wave_sum(T.cnt.fine_probes);
-        if (lane == 0 && A.stats) {
-            atomicAdd(&A.stats[kStatCoarseProbes], p0);
-            atomicAdd(&A.stats[kStatBrickEntries], p1);
-            atomicAdd(&A.stats[kStatFineProbes], p2);
-            atomicAdd(&A.stats[kStatDbgIters], dg_iters);
-            atomicAdd(&A.stats[kStatDbgWalkLanes], dg_walk);
-            atomicAdd(&A.stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);
-            atomicAdd(&A.stats[kStatDbgEndRuns], (unsigned long long)dg_runs[1]);
-            atomicAdd(&A.stats[kStatDbgBoxRuns], (unsigned long long)dg_runs[2]);
-            atomicAdd(&A.stats[kStatDbgNextLanes], (unsigned long long)dg_lanes[0]);
-            atomicAdd(&A.stats[kStatDbgEndLanes], (unsigned long long)dg_lanes[1]);
-            atomicAdd(&A.stats[kStatDbgBoxLanes], (unsigned long long)dg_lanes[2]);
-            atomicAdd(&A.stats[kStatDbgLifetime], wall_clock64() - dg_t0);
-            atomicAdd(&A.stats[kStatDbgDrained], dg_drain);
-            atomicAdd(&A.stats[kStatDbgNextTicks], dg_next_ticks);
-            atomicAdd(&A.stats[kStatDbgParkTicks], dg_park_ticks);
+        if (lane == 0 && A_kern.stats) {
+            atomicAdd(&A_kern.stats[kStatCoarseProbes], p0);
+            atomicAdd(&A_kern.stats[kStatBrickEntries], p1);
+            atomicAdd(&A_kern.stats[kStatFineProbes], p2);
+            atomicAdd(&A_kern.stats[kStatDbgIters], dg_iters);
+            atomicAdd(&A_kern.stats[kStatDbgWalkLanes], dg_walk);
+            atomicAdd(&A_kern.stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);
+            atomicAdd(&A_kern.stats[kStatDbgEndRuns], (unsigned long long)dg_runs[1]);
+            atomicAdd(&A_kern.stats[kStatDbgBoxRuns], (unsigned long long)dg_runs[2]);
+            atomicAdd(&A_kern.stats[kStatDbgNextLanes], (unsigned long long)dg_lanes[0]);
+            atomicAdd(&A_kern.stats[kStatDbgEndLanes], (unsigned long long)dg_lanes[1]);
+            atomicAdd(&A_kern.stats[kStatDbgBoxLanes], (unsigned long long)dg_lanes[2]);
+            atomicAdd(&A_kern.stats[kStatDbgLifetime], wall_clock64() - dg_t0);
+            atomicAdd(&A_kern.stats[kStatDbgDrained], dg_drain);
+            atomicAdd(&A_kern.stats[kStatDbgNextTicks], dg_next_ticks);
+            atomicAdd(&A_kern.stats[kStatDbgParkTicks], dg_park_ticks);
         }
     }
 }
