@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
     ap.add_argument("--views-per-step", type=int, default=16,
                     help="views rendered by one launch (vxrt_render_views); 1 = one RenderScreen-style launch per frame")
+    ap.add_argument("--kernel-variant", type=int, default=4, choices=[1, 2, 4, 5, 6],
+                    help="render kernel (vxrt_set_kernel_variant): 4 = the library's per-launch policy (default); 6 = the "
+                         "traversal / shading pipeline; for A/B runs")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
     ap.add_argument("--bounce-depth", type=int, default=1, help="2 = second bounce (BASELINE config 5; extension beyond the reference)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -141,6 +144,8 @@ def run(args):
 
     X, Y, Z, F, gen, W, H, shadow, bounce = WORKLOADS[args.workload]
     ctx = vx.Context(local_rank)
+    if args.kernel_variant != 4:
+        ctx.set_kernel_variant(args.kernel_variant)
     t_build0 = time.time()
     info = ctx.build_world(gen, X, Y, Z, F)  # every rank builds its own replica in its HBM
     ctx.synchronize()
@@ -282,17 +287,11 @@ def run(args):
     # never more than two frames ahead (what Graphics::RenderScreenAsync / WaitFrame of the C++ facade does)
     dt2 = None
     if V > 1 and world == 1 and not args.force_gather:
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")  # the runtime torch has already loaded
-        raw = []
-        for _ in range(2):
-            h = ctypes.c_void_p()
-            if hip.hipStreamCreateWithFlags(ctypes.byref(h), 1) != 0:  # hipStreamNonBlocking
-                raw = []
-                break
-            raw.append(h.value)
+        # two non-blocking streams from torch itself (its pool streams are created hipStreamNonBlocking): the handles go to
+        # libvxrt through the C ABI, and torch and the library share the one HIP runtime torch loaded
+        ext = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        raw = [st_.cuda_stream for st_ in ext]
         if raw:
-            ext = [torch.cuda.ExternalStream(r) for r in raw]
             done = [torch.cuda.Event() for _ in range(3)]
             ring = torch.zeros((3, H, W, 4), dtype=torch.uint8, device=dev)
             o = opts()
@@ -312,8 +311,6 @@ def run(args):
             dt2 = time.perf_counter() - t2
             s2 = ctx.frame_stats()
             assert s2.total_rays() == rays_local, "ray counts differ between multi-view and two-in-flight launches"
-            for r in raw:
-                hip.hipStreamDestroy(ctypes.c_void_p(r))
 
     result = None
     if rank == 0:
@@ -323,19 +320,35 @@ def run(args):
         n_launch = args.steps * world
         avg_kernel_s = kernel_ms_total / 1e3 / n_launch
         achieved = (bytes_total / n_launch) / avg_kernel_s / 1e9
+        # PMC-derived fields come from a profile kept in profiles/traffic.json (tools/prof.sh + tools/make_traffic_entry.py).
+        # They are reported only when that profile was taken with THIS library (content hash of its sources) and THIS
+        # kernel; anything else is stale: null, and "stale_profile": true says why.
         traffic = None
         issue = None
+        stale_profile = None
+        kernel_id = ctx.kernel_for_launch(W, H, opts(), V if V > 1 else 0)
+        kernel_symbol = "%s<false,%s,%s>" % (ctx.KERNEL_NAMES[kernel_id], "true" if args.bounce_depth == 2 else "false",
+                                             "true" if V > 1 else "false")
+        if kernel_id == 6:  # the traversal / shading pipeline: the step's launch time covers k_ts_gen + per generation T and S
+            kernel_symbol = "k_ts_trace<false> (+ k_ts_gen, k_ts_shade<%s>: one T and one S launch per ray generation)" % (
+                "true" if args.bounce_depth == 2 else "false")
         tj = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tj):
+        if os.path.exists(tj) and world == 1:
             try:
                 # profiled launch shapes: the default batch (entry `workload`, which names its views_per_launch) and V = 1
                 tab = json.load(open(tj))
                 ent = tab.get(args.workload + "_single_view_launch", {}) if V == 1 else tab.get(args.workload, {})
-                if world == 1 and ent.get("views_per_launch", 1 if V == 1 else None) == V:
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    issue = ent.get("issue_utilisation")
+                if ent.get("views_per_launch", 1 if V == 1 else None) == V:
+                    hash_file = vx.lib_path() + ".srchash"
+                    lib_hash = open(hash_file).read().strip() if os.path.exists(hash_file) else None
+                    if lib_hash and ent.get("lib_srchash") == lib_hash and ent.get("kernel_symbol") == kernel_symbol.replace(" ", ""):
+                        traffic = ent.get("hbm_bytes_per_launch")
+                        issue = ent.get("issue_utilisation")
+                        stale_profile = False
+                    else:
+                        stale_profile = True
             except Exception:
-                traffic = None
+                traffic, issue, stale_profile = None, None, None
         result = {
             "metric": "Mrays/s primary+1-bounce @1080p, 8k×512×8k brickmap; % HBM roofline",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -354,9 +367,7 @@ def run(args):
                 if world > 1 else "none", "rays_per_step": round(rays_total / args.steps, 1),
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
             },
-            "roofline": {"bound": "hbm", "kernel": "%s<false,%s,%s>" % (
-                             ctx.KERNEL_NAMES[ctx.kernel_for_launch(W, H, opts(), V if V > 1 else 0)],  # the library's choice
-                             "true" if args.bounce_depth == 2 else "false", "true" if V > 1 else "false"),
+            "roofline": {"bound": "hbm (algorithmic-bytes convention)", "kernel": kernel_symbol,  # the library's choice
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(bytes_total / n_launch, 1),
@@ -368,10 +379,9 @@ def run(args):
                          "convention": "achieved = algorithmic bytes (SURVEY.md 8d: 28 B per coarse probe, 24 B per brick entry, "
                                        "4 B per brick probe, 4 B per pixel) / launch time; not measured HBM traffic",
                          "traffic_frac": None if traffic is None else round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
-                         "physical_bound": "instruction issue per wavefront at 5 waves/SIMD (divergent traversal); "
-                                           "issue_utilisation = instructions issued per SIMD cycle against the rate the same "
-                                           "instruction mix reaches in profiles/r02b_issue_rate_ubench.txt",
-                         "issue_utilisation": issue},
+                         "physical_bound": "instruction issue (divergent traversal): the launch time follows the issued instruction "
+                                           "count at ~2.3 cycles per instruction per SIMD, whatever the waves per SIMD (5 and 6 measured)",
+                         "issue_utilisation": issue, "stale_profile": stale_profile},
         }
         if rehearse or args.force_gather:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
             full = torch.zeros_like(frames)

@@ -142,7 +142,12 @@ int vxrt_world_file_info(const char *path, vxrt_world_info *out);
  *   vxrt_stream_focus: makes every chunk whose box lies within `radius` voxels of `focus` resident, nearest first;
  *     when the pool is full, resident chunks OUTSIDE the radius are evicted, farthest first; chunks inside the radius
  *     that still do not fit stay absent (stats.chunks_missing).  Synchronises the device before it touches the tables.
- *   vxrt_stream_resident: one byte per chunk (chunk = tile index of the coarse grid), 1 = resident. */
+ *   vxrt_stream_resident: one byte per chunk (chunk = tile index of the coarse grid), 1 = resident.
+ * The coarse tables are validated at open exactly as vxrt_load_world validates them (sizes, position-sensitive sums, slots
+ * in cell order, brick extents); brick data read per chunk is NOT checksummed (the file's pool sum covers the whole
+ * stream, not its chunks).  vxrt_download_world / vxrt_save_world on a streamed world give the CACHE as it stands: the
+ * resident chunks' cells with the cache's own slot numbers, every other cell empty, the pool zero where nothing has been
+ * loaded (it is cleared at open) and stale, unreferenced bricks where chunks have been evicted. */
 typedef struct vxrt_stream_stats {
     uint64_t chunks_total, chunks_occupied;   /* tiles of the coarse grid; those holding at least one brick */
     uint64_t chunks_resident, bricks_resident;
@@ -252,6 +257,11 @@ uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_co
  * the device (every stream).  The device-side counters only grow: "since the previous read" is a host-side snapshot, so a
  * read never clears memory that a running kernel adds to. */
 int vxrt_frame_stats_get(vxrt_ctx *ctx, vxrt_frame_stats *out);
+/* Diagnostics of the experiments build (libvxrt_exp.so; zeros from the product library): histogram over the wave-loop
+ * iterations of probe-counting launches (collect_stats) since the previous read -- out[n] = iterations in which the lanes of
+ * a wavefront that were walking inside a brick sat in n DISTINCT bricks, n = 0..64; out[65 + n] = the same count over the
+ * iterations in which no lane walked on the coarse grid (profiles/r03_mechanisms_ab.md). */
+int vxrt_debug_brick_histogram(vxrt_ctx *ctx, uint64_t out[130]);
 /* scatter `strip_count` compact shard buffers (laid out back to back, shard-major, each padded to
  * `shard_stride_bytes`) into a full W*H BGRA8 frame on the device; used by the root after the gather. */
 int vxrt_deinterleave_strips(vxrt_ctx *ctx, uint32_t width, uint32_t height, int32_t strip_rows,

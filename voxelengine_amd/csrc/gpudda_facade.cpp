@@ -116,14 +116,26 @@ std::ostream& operator<<(std::ostream& os, const BitArray& bits)
 
 // ---- VoxelRaytracer3D ------------------------------------------------------------------------------
 
+static int g_live_raytracers = 0;  // RenderScreenAsync's streams live as long as some raytracer does (see FrameSlots)
+
 VoxelRaytracer3D::VoxelRaytracer3D(size_t /*count*/)
 {
     int device = 0;
     (void)hipGetDevice(&device);
     ok(vxrt_create(device, &ctx), "vxrt_create");
+    ++g_live_raytracers;
 }
 
-VoxelRaytracer3D::~VoxelRaytracer3D() { Free(); }
+namespace Graphics {
+static void release_frame_slots();
+}
+
+VoxelRaytracer3D::~VoxelRaytracer3D()
+{
+    Free();
+    if (--g_live_raytracers == 0)
+        Graphics::release_frame_slots();  // while the HIP runtime is certainly still up: never from a static destructor
+}
 
 void VoxelRaytracer3D::Free()
 {
@@ -357,16 +369,24 @@ void RenderScreen(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void* d_screen_t
 
 // ---- two frames in flight (RenderScreenAsync / WaitFrame) ---------------------------------------------------------
 namespace {
+// The two streams of RenderScreenAsync.  Process-wide like the reference's Graphics state (Renderer.cu:24-25,89), but tied to
+// a DEVICE (streams of one device must not carry another device's launches: a raytracer on another device gets fresh ones)
+// and released with the last VoxelRaytracer3D, not by a static destructor (that would run after the HIP runtime's own
+// teardown).
 struct FrameSlots {
     hipStream_t stream[2] = {nullptr, nullptr};
     hipEvent_t done[2] = {nullptr, nullptr};
+    int device = -1;
     FrameTicket issued = 0;  // tickets count from 1; ticket t uses slot t % 2
-    ~FrameSlots()
+    void release()
     {
         for (int i = 0; i < 2; ++i) {
             if (done[i]) (void)hipEventDestroy(done[i]);
             if (stream[i]) (void)hipStreamDestroy(stream[i]);
+            done[i] = nullptr;
+            stream[i] = nullptr;
         }
+        device = -1;
     }
 };
 FrameSlots g_frames;
@@ -385,6 +405,15 @@ FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void
 {
     vxrt_render_flags fl;
     vxrt_ctx* c = prepare_launch(rt, fl);
+    int device = 0;
+    hip_ok(hipGetDevice(&device), "hipGetDevice");
+    if (g_frames.device != device) {  // first use, or a raytracer on another device: finish and drop the old device's pair
+        for (int i = 0; i < 2; ++i)
+            if (g_frames.done[i])
+                (void)hipEventSynchronize(g_frames.done[i]);
+        g_frames.release();
+        g_frames.device = device;
+    }
     const FrameTicket t = ++g_frames.issued;
     const int s = (int)(t % 2);
     if (!g_frames.stream[s]) {
@@ -404,14 +433,22 @@ FrameTicket RenderScreenAsync(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, void
 
 void WaitFrame(FrameTicket t)
 {
-    if (t == 0 || t > g_frames.issued)
-        return;  // never issued
+    if (t == 0 || t > g_frames.issued || !g_frames.done[t % 2])
+        return;  // never issued (or its streams went with the last raytracer, which waited for them)
     // the event of the newest frame on t's stream: frames of one parity complete in order, so this covers frame t (and
     // waits for a later frame of the same parity if the caller has already launched one)
     hip_ok(hipEventSynchronize(g_frames.done[t % 2]), "hipEventSynchronize");
 }
 
 void* FrameStream(FrameTicket t) { return g_frames.stream[t % 2]; }
+
+static void release_frame_slots()
+{
+    for (int i = 0; i < 2; ++i)
+        if (g_frames.done[i])
+            (void)hipEventSynchronize(g_frames.done[i]);
+    g_frames.release();
+}
 
 void RenderScreens(VoxelRaytracer3D* rt, uint32_t w, uint32_t h, const ScreenView* views, uint32_t count)
 {

@@ -859,7 +859,7 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     VX_HIP(hipDeviceSynchronize());  // every stream of the device, non-blocking ones included
     unsigned long long now[vxrt::kStatCount], h[vxrt::kStatCount];
     VX_HIP(hipMemcpy(now, c->d_stats, sizeof(now), hipMemcpyDeviceToHost));
-    for (int i = 0; i < vxrt::kStatCount; ++i) {  // what was added since the previous read; the device copy only grows
+    for (int i = 0; i < vxrt::kStatBrickHist; ++i) {  // what was added since the previous read; the device copy only grows
         h[i] = now[i] - c->stats_base[i];
         c->stats_base[i] = now[i];
     }
@@ -882,6 +882,22 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     out->dbg[9] = h[vxrt::kStatDbgDrained];
     out->dbg[10] = h[vxrt::kStatDbgNextTicks];
     out->dbg[11] = h[vxrt::kStatDbgParkTicks];
+    return VXRT_OK;
+}
+
+int vxrt_debug_brick_histogram(vxrt_ctx* c, uint64_t out[130])
+{
+    static_assert(vxrt::kStatBrickHistFineOnly == vxrt::kStatBrickHist + 65 && vxrt::kStatCount == vxrt::kStatBrickHist + 130, "histogram layout");
+    if (!c || !out)
+        return fail(VXRT_ERR_INVALID, "NULL argument");
+    VX_HIP(hipSetDevice(c->device));
+    VX_HIP(hipDeviceSynchronize());
+    unsigned long long now[130];
+    VX_HIP(hipMemcpy(now, c->d_stats + vxrt::kStatBrickHist, sizeof(now), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 130; ++i) {  // since the previous read, like vxrt_frame_stats_get
+        out[i] = now[i] - c->stats_base[vxrt::kStatBrickHist + i];
+        c->stats_base[vxrt::kStatBrickHist + i] = now[i];
+    }
     return VXRT_OK;
 }
 
@@ -1082,6 +1098,20 @@ struct FileCloser {
     ~FileCloser() { if (f) fclose(f); }
 };
 
+// tight extents of an occupied cell's record: six 5-bit fields {min x,y,z, max x,y,z}, each inside the brick, min <= max,
+// nothing above them (shared by vxrt_load_world and vxrt_stream_open)
+bool extents_valid(uint32_t packed, int factor)
+{
+    if ((packed >> 30) != 0u)
+        return false;
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t lo = (packed >> (5 * a)) & 31u, hi = (packed >> (5 * (a + 3))) & 31u;
+        if (hi >= (uint32_t)factor || lo > hi)
+            return false;
+    }
+    return true;
+}
+
 int read_header(FILE* f, const char* path, FileHeader& h)
 {
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, kFileMagic, 8) != 0)
@@ -1247,12 +1277,8 @@ int vxrt_load_world(vxrt_ctx* c, const char* path)
                     const bool bit = (coarse[cell >> 5] >> (cell & 31)) & 1u;
                     if (bit ? m[i].x >= h.nslots : m[i].x != VXRT_EMPTY_SLOT)
                         return bad("cell table does not match the coarse bits / pool size");
-                    if (bit)  // tight extents: six 5-bit fields {min x,y,z, max x,y,z}, each inside the brick, min <= max
-                        for (int a = 0; a < 3; ++a) {
-                            const uint32_t lo = (m[i].y >> (5 * a)) & 31u, hi = (m[i].y >> (5 * (a + 3))) & 31u;
-                            if (hi >= (uint32_t)h.factor || lo > hi || (m[i].y >> 30) != 0u)
-                                return bad("brick extents outside the brick");
-                        }
+                    if (bit && !extents_valid(m[i].y, h.factor))
+                        return bad("brick extents outside the brick");
                 }
             }
             e = hipMemcpy(static_cast<unsigned char*>(dst[t]) + off, stage.data(), n, hipMemcpyHostToDevice);
@@ -1396,6 +1422,8 @@ int vxrt_stream_open(vxrt_ctx* c, const char* path, uint64_t pool_capacity_brick
             // bricks are ONE contiguous run
             if (bit ? S->meta[i].x != next_slot : S->meta[i].x != VXRT_EMPTY_SLOT)
                 return bad(VXRT_ERR_INVALID, std::string(path) + ": brick slots are not in cell order");
+            if (bit && !extents_valid(S->meta[i].y, h.factor))  // (what vxrt_load_world checks of a cell record)
+                return bad(VXRT_ERR_INVALID, std::string(path) + ": brick extents outside the brick");
             if (bit) {
                 ++next_slot;
                 ++C.nbricks;
@@ -1423,6 +1451,8 @@ int vxrt_stream_open(vxrt_ctx* c, const char* path, uint64_t pool_capacity_brick
     }
     std::vector<uint2> empty(h.ncells, make_uint2(VXRT_EMPTY_SLOT, 0u));
     hipError_t e = hipMemset(c->d_coarse, 0, h.coarse_bytes);
+    if (e == hipSuccess)  // the cache pool starts as empty space, not as whatever the allocation held
+        e = hipMemset(c->d_pool, 0, pool_capacity_bricks * S->brick_bytes);
     if (e == hipSuccess)
         e = hipMemcpy(c->d_meta, empty.data(), h.meta_bytes, hipMemcpyHostToDevice);
     if (e == hipSuccess)

@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
     }
 
     TraceResult pr;
-    trace_wave<STATS>(A.W, kMaxSteps, live, origin, ray, pr, cnt);
+    unsigned long long* const bh = (STATS && A.stats) ? A.stats + kStatBrickHist : nullptr;  // (experiments build diagnostics)
+    trace_wave<STATS>(A.W, kMaxSteps, live, origin, ray, pr, cnt, nullptr, nullptr, false, bh);
     n_primary = live ? 1u : 0u;
     const bool hit = live && pr.hit;
     n_hits = hit ? 1u : 0u;
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
     bool shadowed = false;
     if (A.shadow) {
         TraceResult ts;
-        trace_wave<STATS>(A.W, kMaxSteps, lit, position + sray * 0.01f, sray, ts, cnt);
+        trace_wave<STATS>(A.W, kMaxSteps, lit, position + sray * 0.01f, sray, ts, cnt, nullptr, nullptr, false, bh);
         shadowed = lit && ts.hit;
         n_shadow = lit ? 1u : 0u;
     }
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
             if (dot3(sd, normal) < 0)
                 sd = reflect3(sd, normal);
             TraceResult tb;
-            trace_wave<STATS>(A.W, 8, gate, position + normal * 0.01f, sd, tb, cnt);
+            trace_wave<STATS>(A.W, 8, gate, position + normal * 0.01f, sd, tb, cnt, nullptr, nullptr, false, bh);
             if (gate) {
                 n_bounce += 1;
                 if (!tb.hit)
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
                 if (dot3(d2, n2) < 0)
                     d2 = reflect3(d2, n2);
                 TraceResult t2;
-                trace_wave<STATS>(A.W, 8, again, tb.pos + n2 * 0.01f, d2, t2, cnt);
+                trace_wave<STATS>(A.W, 8, again, tb.pos + n2 * 0.01f, d2, t2, cnt, nullptr, nullptr, false, bh);
                 if (again) {
                     n_bounce += 1;
                     if (!t2.hit)

@@ -26,7 +26,15 @@ enum StatSlot {
     kStatDbgDrained,    // persistent kernel: iterations after the tile queue ran dry
     kStatDbgNextTicks,  // persistent kernel: 100 MHz ticks inside the ray-finished phase, summed over waves
     kStatDbgParkTicks,  // ... inside the box and end-of-walk phases
-    kStatCount
+    // Experiments build, probe-counting launches: histogram over wave-loop iterations of the number of DISTINCT bricks among
+    // the lanes that walk inside a brick in that iteration (bins 0..64), for primary-, shadow- and bounce-stage lanes kept
+    // apart where the kernel knows the stage (the fused kernels; T and the wave kernel count everything under "all")
+    kStatBrickHist,
+    kStatBrickHistEnd = kStatBrickHist + 65,
+    // ... and the same histogram over the iterations in which NO lane walks on the coarse grid (every occupancy word of the
+    // iteration's probes comes from those n bricks: what a wave-level brick cache of n entries could serve alone)
+    kStatBrickHistFineOnly = kStatBrickHistEnd,
+    kStatCount = kStatBrickHistFineOnly + 65
 };
 
 constexpr unsigned kMaxScheduledTileRows = 512;  // frames up to 4096 launch rows get a tile schedule

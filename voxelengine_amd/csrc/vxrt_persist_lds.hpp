@@ -153,6 +153,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST_LDS_OCC) void k_render_persist_lds
             dg_iters += 1;
             dg_walk += (unsigned long long)n_walk;
             dg_drain += drained ? 1ull : 0ull;
+#ifdef VXRT_EXPERIMENTS
+            if (A_kern.stats)
+                brick_histogram(W, T, A_kern.stats + kStatBrickHist);
+#endif
         }
 
         // The parked phases run box -> end -> next inside one round, each vote on fresh counts: a lane whose box test

@@ -122,6 +122,10 @@ __global__ __launch_bounds__(64, VXRT_TS_OCC) void k_ts_trace(TsTraceArgs B)
         if (STATS) {
             dg_iters += 1;
             dg_walk += (unsigned long long)c_walk;
+#ifdef VXRT_EXPERIMENTS
+            if (B.stats)
+                brick_histogram(W, T, B.stats + kStatBrickHist);
+#endif
         }
         if (vote_run(c_box, c_walk, VXRT_VOTE_BOX)) {
             if (STATS) {

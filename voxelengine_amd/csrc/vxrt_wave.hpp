@@ -703,11 +703,37 @@ __device__ __forceinline__ PreparedRay prepare_ray(const WorldView& W, const f3 
     return r;
 }
 
+#if defined(VXRT_EXPERIMENTS) && !defined(VXRT_HOST_CHECK)
+// Diagnostics: how many DISTINCT bricks do the lanes of this wave walk in right now?  One loop
+// pass per distinct brick (readfirstlane of a lane's brick, ballot of the lanes in the same one); bin `n` of `hist` counts
+// the iterations with n distinct bricks.  Probe-counting launches only.
+template <class Tracer>
+__device__ __forceinline__ void brick_histogram(const WorldView& W, const Tracer& T, unsigned long long* hist)
+{
+    const bool in_brick = T.st == ST_WALK && T.fine != 0u;
+    const uint32_t key = (uint32_t)((T.bits - W.pool) / W.brick_words);
+    unsigned long long m = __ballot(in_brick);
+    uint32_t n = 0;
+    while (m != 0ull) {
+        const int first = __ffsll((long long)m) - 1;
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)key, first);
+        m &= ~__ballot(in_brick && key == k0);
+        n += 1u;
+    }
+    const bool coarse_walkers = __ballot(T.st == ST_WALK && T.fine == 0u) != 0ull;
+    if ((threadIdx.x & 63) == 0 && hist) {
+        atomicAdd(&hist[n], 1ull);
+        if (!coarse_walkers)
+            atomicAdd(&hist[65 + n], 1ull);  // (kStatBrickHistFineOnly follows kStatBrickHist)
+    }
+}
+#endif
+
 // one ray per lane, entered by the whole wave at a converged point
 template <bool STATS, bool MASKED_LOAD = false, bool LDS_COLD = false>
 __device__ void trace_wave(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
                            TraceResult& out, RayCounters& cnt, unsigned int* dbg = nullptr, uint32_t* cold_column = nullptr,
-                           const bool prepared = false)
+                           const bool prepared = false, unsigned long long* brick_hist = nullptr)
 {
     WaveTracer<STATS, MASKED_LOAD, LDS_COLD> T;
     T.init(W, cold_column);
@@ -741,6 +767,10 @@ __device__ void trace_wave(const WorldView& W, const int max_steps, const bool a
         }
         if (STATS)
             cnt.walk_lanes += (uint32_t)__popcll(__ballot(T.st == ST_WALK));
+#if defined(VXRT_EXPERIMENTS) && !defined(VXRT_HOST_CHECK)
+        if (STATS && brick_hist)
+            brick_histogram(W, T, brick_hist);
+#endif
         if (STATS && dbg && cnt.iters <= 400u) {  // development trace of one lane (the caller passes dbg for lane 0 only)
             unsigned int* row = dbg + (cnt.iters - 1u) * 12u;
             row[0] = T.st; row[1] = T.fine; row[2] = (unsigned)T.cell_x; row[3] = (unsigned)T.cell_y; row[4] = (unsigned)T.cell_z;

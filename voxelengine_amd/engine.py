@@ -298,6 +298,14 @@ class Context:
         grid so that modest batches take the queue kernel."""
         N.check(self._L.vxrt_set_persistent_waves_per_cu(self._h, int(waves_per_cu)))
 
+    def brick_histogram(self) -> np.ndarray:
+        """Experiments build: out[n] = wave-loop iterations (probe-counting launches since the previous read) in which the
+        lanes walking inside a brick sat in n distinct bricks (n = 0..64); out[65 + n]: the same over the iterations with no
+        lane on the coarse grid."""
+        out = np.zeros(130, np.uint64)
+        N.check(self._L.vxrt_debug_brick_histogram(self._h, out.ctypes.data))
+        return out
+
     def has_experiments(self) -> bool:
         """True for the A/B build of the library (variants 0 and 3, knobs from the environment)."""
         return bool(self._L.vxrt_has_experiments())
