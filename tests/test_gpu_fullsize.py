@@ -3,7 +3,8 @@ the oracle cannot render whole frames in test time: size-independent properties 
   * a random sample of the frame's primary rays: HIP batch trace == oracle (bit-exact), on the downloaded bricks
   * the two entry points agree: hit voxel AOV of vxrt_render == vxrt_trace_batch of the same camera rays
   * idempotence: the same frame rendered twice is byte-identical
-  * the three separately written kernels (variants 0, 1, 2) produce the same frame
+  * oracle-rendered bands of the shaded 1080p frame, every render kernel of the product and a 16-view launch
+  * the separately written kernels (variants 1, 2, 5, 6) produce the same frame
   * 8 interleaved strip shards reassemble into the single-GPU frame
   * ray accounting: shadow rays == primary hits; rays <= 3 * pixels
 """
@@ -72,6 +73,47 @@ def test_render_and_batch_entry_points_agree(big, cam):
     b = ctx.Raytrace(o, d.reshape(-1, 3))
     assert np.array_equal(b["voxel"].reshape(H, W), hit.cpu().numpy())
     assert int(b["hit"].sum()) == st.primary_hits
+
+
+def test_shaded_1080p_frame_bands_against_the_oracle(big, vxo):
+    """BASELINE configs[2] itself -- the bench workload: 1080p, primary + shadow + 1 bounce on the 8192x512x8192 world --
+    against oracle-rendered BANDS of the shaded frame (sky / horizon rows, terrain rows, the last rows), for two cameras,
+    through every render kernel of the product and through a 16-view launch (bench.py's step)."""
+    vx, ctx, torch, info = big
+    w = ctx.download_world()
+    world = vxo.World.wrap(w["factor"], w["cdims"], w["coarse_bits"], w["brick_slot"], w["bounds"], w["pool"])
+    default = ctx.kernel_variant
+    bands = ((0, 16), (520, 552), (H - 16, H))
+    try:
+        for cam, fn in (("A", 3), ("D", 8)):
+            pos, fwd, up, right, _ = _camera_rays(vx, cam)
+            refs = []
+            for r0, r1 in bands:
+                refs.append(world.render(vxo.make_params(W, H, pos, fwd, up, right, frame_number=fn, shadow=1, bounce_samples=1,
+                                                         row_begin=r0, row_end=r1), fb=np.zeros((H, W, 4), np.uint8),
+                                         want_hit=True, nthreads=16))
+            for variant in (4, 5, 6, 2, 1):
+                ctx.set_kernel_variant(variant)
+                fb = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+                hit = torch.full((H, W), -1, dtype=torch.int64, device="cuda")
+                ctx.RenderScreen(W, H, fb, pos, fwd, up, right, vx.RenderOptions(shadow=True, bounce_samples=1, frame_number=fn),
+                                 hit_aov=hit)
+                got, ghit = fb.cpu().numpy(), hit.cpu().numpy()
+                for (r0, r1), ref in zip(bands, refs):
+                    assert np.array_equal(got[r0:r1], ref["fb"][r0:r1]), (cam, variant, r0)
+                    assert np.array_equal(ghit[r0:r1], ref["hit"][r0:r1]), (cam, variant, r0)
+            # the same view as one of 16 in a multi-view launch (default policy and the traversal / shading pipeline)
+            for variant in (4, 6):
+                ctx.set_kernel_variant(variant)
+                fbs = torch.zeros((16, H, W, 4), dtype=torch.uint8, device="cuda")
+                views = [dict(fb=fbs[j], origin=pos, fwd=fwd, up=up, right=right, frame_number=fn + (j != 5)) for j in range(16)]
+                ctx.RenderViews(W, H, views, vx.RenderOptions(shadow=True, bounce_samples=1))
+                got = fbs[5].cpu().numpy()
+                for (r0, r1), ref in zip(bands, refs):
+                    assert np.array_equal(got[r0:r1], ref["fb"][r0:r1]), (cam, variant, "multi-view", r0)
+    finally:
+        ctx.set_kernel_variant(default)
+        ctx.frame_stats()
 
 
 def test_sampled_rays_against_oracle_on_the_full_world(big, vxo):
