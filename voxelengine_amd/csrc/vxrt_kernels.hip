@@ -595,7 +595,9 @@ int ts_generations(const RenderArgs& A)
 // chain's T would fill the other's low-occupancy tail and the bandwidth-bound S kernels would run beside a T.  Chains that
 // do the same work stay in lockstep -- every T is a persistent grid of the whole chip, so two of them split the wave slots
 // instead of following each other -- and more, smaller launches pay more ramps and tails than they hide: 1 / 2 / 4 streams
-// x 1 / 4 / 16 parts = 14.7 / 15.0 / 19.0 ms per 16-view step, 16 parts on one stream 31.9; profiles/r03_ts_pipeline.md.)
+// x 1 / 4 / 16 parts = 14.7 / 15.0 / 19.0 ms per 16-view step, 16 parts on one stream 31.9.  Two chains STAGGERED by one
+// traversal (the second chain's first T waits for the first chain's, so that one chain traces while the other shades):
+// 14.88 ms against 14.60 with one chain.  profiles/r03_ts_pipeline.md.)
 hipError_t launch_render_ts(const RenderArgs& A, const TsArgs& S, bool stats, hipStream_t stream)
 {
     static_assert(kTsShards == VXRT_TS_SHARDS, "queue shards");
