@@ -52,7 +52,10 @@ int vxrt_synchronize(vxrt_ctx *ctx);
  *   2 = persistent waves, one pixel chain per lane, pixels from a tile queue;
  *   5 = 2 with the state only the parked phases touch in LDS: 96 VGPRs, 5 waves per SIMD;
  *   6 = wavefront pipeline: a traversal kernel and a shading kernel that hand each other prepared ray records through HBM,
- *       generation by generation (primary, shadow, bounce): measured within 3 % of 5 on 16-view launches, slower on one view;
+ *       generation by generation (primary, shadow, bounce): measured 5 % behind 5 on 16-view launches, 40 % behind on one
+ *       view.  Its queues live in a workspace of 178 bytes per pixel of the launch (186 with a hit-index
+ *       AOV), taken from a ring of three per context: a fourth variant-6 launch in flight waits for the oldest; the first
+ *       launch of a shape allocates, so it cannot happen inside a stream capture;
  *   1 = straightforward per-lane loops (the on-device cross-check).
  * Variants 0 (wave-level state machine, one lane per pixel) and 3 (pixel chains pooled in LDS) are A/B kernels of the
  * experiments build (libvxrt_exp.so) and are refused by the product library.  (Batch traces: 1 = straightforward,

@@ -101,7 +101,7 @@ while time.time() < t_end:
             fail("multi-view launch, view %d" % j, seed, "cam %s %dx%d %r" % (cam, W, H, kw))
     ctx.set_kernel_variant(4)
     ctx.frame_stats()
-    frames_checked += 8
+    frames_checked += (6 if ctx.has_experiments() else 4) + 3
     rounds += 1
     if rounds % 10 == 0:
         print("round %d (seed %d): %d rays, %d frames checked, all equal" % (rounds, seed, rays_checked, frames_checked), flush=True)
