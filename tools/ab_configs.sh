@@ -1,14 +1,14 @@
 #!/bin/bash
 # usage: tools/ab_configs.sh <out-tag> <variant> ...   (on the GPU box via gpurun)
-# the BASELINE configurations other than bench.py's default, each with the given render kernel variants (VXRT_VARIANT)
+# the BASELINE configurations other than bench.py's default, each with the given render kernel variants
+# (bench.py --kernel-variant: 4 = the library's policy, 2, 5, 6, 1)
 set -o pipefail
-# VXRT_VARIANT / VXRT_WAVES_PER_CU are read by the EXPERIMENTS build only: make -C voxelengine_amd/csrc libvxrt_exp.so first
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/abc_$1; shift
 mkdir -p $OUT
 for w in ${WORKLOADS:-c2_1k_1080p_primary c3_f8_variant c4_8k_4k_shadow_bounce c5_16k_4k_shadow_bounce}; do
   for v in "$@"; do
-    VXRT_VARIANT=$v python3 $R/bench.py --cpu-baseline off --workload $w --steps ${STEPS:-6} --warmup 1 > $OUT/${w}_v$v.json 2> $OUT/${w}_v$v.err || { echo "$w v$v failed"; tail -20 $OUT/${w}_v$v.err; echo "stopping: no further GPU run behind a failed one"; exit 1; }
+    python3 $R/bench.py --cpu-baseline off --kernel-variant $v --workload $w --steps ${STEPS:-6} --warmup 1 > $OUT/${w}_v$v.json 2> $OUT/${w}_v$v.err || { echo "$w v$v failed"; tail -20 $OUT/${w}_v$v.err; echo "stopping: no further GPU run behind a failed one"; exit 1; }
     python3 - "$OUT/${w}_v$v.json" "$w v$v" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
