@@ -244,15 +244,19 @@ def test_batch_max_steps_matches_the_oracle(eng, vxo):
         small.close()
 
 
+@pytest.mark.parametrize("variant", [4, 6])
 @pytest.mark.parametrize("depth", [1, 2])
-def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth):
+def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth, variant):
     """More launches in flight than the context has queue heads (64 single-view, 16 multi-view): launch 65 waits for launch 1
     instead of sharing its tile counter (vxrt_api.hip ring_acquire).  80 single-view launches and 20 multi-view launches
     over 4 streams, no synchronisation in between; every frame must be the frame a lone launch renders, and the ray
-    counters must add up.  depth 2 = the second-bounce instantiation of the kernels (the one with the most private state)."""
+    counters must add up.  depth 2 = the second-bounce instantiation of the kernels (the one with the most private state).
+    variant 6 = the traversal / shading pipeline, whose ray queues come from a ring of THREE workspaces per context: launch 4
+    waits for launch 1, and the multi-view launches behind the single-view ones make every ring entry grow."""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
+    ctx.set_kernel_variant(variant)
     W, H = 200, 120
     cams = [helpers.camera(c, w.dims, vxo) for c in "ABCD"]
     inv = float(np.float32(1.0) / np.sqrt(np.float32(3.0)))
@@ -289,6 +293,7 @@ def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth):
     for k in range(20):
         for j in range(4):
             assert torch.equal(mv[k, j], ref[j]), (k, j)
+    ctx.set_kernel_variant(4)
 
 
 def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
