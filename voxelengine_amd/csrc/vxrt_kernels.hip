@@ -607,7 +607,7 @@ hipError_t launch_render_ts(const RenderArgs& A, const TsArgs& S, bool stats, hi
     hipError_t e = hipMemsetAsync(S.tickets, 0, (size_t)gens * kTsShards * 64u * sizeof(unsigned int), stream);
     if (e != hipSuccess)
         return e;
-    const unsigned cus = A.persistent_waves / 16u;
+    const unsigned cus = std::max(1u, A.persistent_waves / 16u);  // (persistent_waves = 16 per CU unless a test shrank the grid)
     const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
     // S: one wave per group, 4 waves per block, at most 8 resident blocks' worth per CU (the loops stride over the groups)
     const unsigned s_blocks = (unsigned)std::min<unsigned long long>(((unsigned long long)S.groups + 3ull) / 4ull, (unsigned long long)cus * 8ull);
@@ -695,7 +695,7 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
         // persistent_waves = 4 per SIMD; variant 5's kernel is built for VXRT_PERSIST_LDS_OCC
-        const unsigned resident = variant == 5 ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST_LDS_OCC : A.persistent_waves;
+        const unsigned resident = std::max(1u, variant == 5 ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST_LDS_OCC : A.persistent_waves);
         const unsigned waves = ntiles < resident ? (unsigned)ntiles : resident;
         const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
