@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
     ap.add_argument("--views-per-step", type=int, default=16,
                     help="views rendered by one launch (vxrt_render_views); 1 = one RenderScreen-style launch per frame")
-    ap.add_argument("--kernel-variant", type=int, default=4, choices=[1, 2, 4, 5, 6],
+    ap.add_argument("--kernel-variant", type=int, default=4, choices=[1, 2, 4, 5, 6, 7],
                     help="render kernel (vxrt_set_kernel_variant): 4 = the library's per-launch policy (default); 6 = the "
                          "traversal / shading pipeline; for A/B runs")
     ap.add_argument("--bounce-all-hits", type=int, default=0)

@@ -143,7 +143,7 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6])
+@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
     """Variants: 1 straightforward per-lane loops, 2 persistent waves with a pixel queue, 5 the same with its cold state
     in LDS, 6 the traversal / shading pipeline over ray queues.  All give the oracle's bits, in every render mode.
@@ -475,7 +475,7 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5, 6, 1])
+@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 1])
 def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
     """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).
     Every view must be byte for byte the frame RenderScreen produces for it -- frame, hit-index AOV and colour AOV --

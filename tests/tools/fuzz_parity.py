@@ -45,7 +45,7 @@ while time.time() < t_end:
     n = int(rng.integers(20000, 120000))
     o, d = helpers.mixed_rays(w.dims, n, seed)
     cpu = w.trace_batch(o, d)
-    for variant in (2, 1):   # batch: variants 0 and 2 share the wave tracer
+    for variant in (2, 1, 7):   # batch: variants 0 and 2 share the wave tracer; 7 = the tracer of vxrt_wave2.hpp
         ctx.set_kernel_variant(variant)
         g = ctx.Raytrace(o, d)
         for k_gpu, k_cpu in (("hit", "hit"), ("steps", "steps"), ("voxel", "voxel")):
@@ -74,7 +74,7 @@ while time.time() < t_end:
     opts = vx.RenderOptions(mode=kw["mode"], checkerboard=bool(kw["checkerboard"]), shadow=bool(kw["shadow"]),
                             bounce_samples=kw["bounce_samples"], bounce_all_hits=bool(kw["bounce_all_hits"]),
                             bounce_depth=kw["bounce_depth"], ortho=bool(kw["ortho"]), frame_number=kw["frame_number"])
-    for variant in ((2, 3, 5, 6, 0, 1) if ctx.has_experiments() else (2, 5, 6, 1)):   # 0 and 3: the experiments build (VXRT_LIB=.../libvxrt_exp.so)
+    for variant in ((2, 3, 5, 6, 7, 0, 1) if ctx.has_experiments() else (2, 5, 6, 7, 1)):   # 0 and 3: the experiments build (VXRT_LIB=.../libvxrt_exp.so)
         ctx.set_kernel_variant(variant)
         d_fb = torch.from_numpy(fb0.copy()).cuda()
         d_hit = torch.full((H, W), -1, dtype=torch.int64, device="cuda")
@@ -85,7 +85,7 @@ while time.time() < t_end:
             fail("hit indices variant %d" % variant, seed, "cam %s %dx%d %r" % (cam, W, H, kw))
     # the same configuration as a multi-view launch: this view plus two others, each against its own oracle frame;
     # alternately through the pixel-per-lane kernel and the LDS pool kernel
-    ctx.set_kernel_variant((2, 6, 5)[seed % 3])
+    ctx.set_kernel_variant((2, 6, 5, 7)[seed % 4])
     views, wants = [], []
     for j in range(3):
         cj = cam if j == 0 else str(rng.choice(["A", "B", "C", "D"]))
@@ -107,5 +107,5 @@ while time.time() < t_end:
         print("round %d (seed %d): %d rays, %d frames checked, all equal" % (rounds, seed, rays_checked, frames_checked), flush=True)
     seed += 1
 
-print("FUZZ OK: %d rounds, %d batch rays (2 kernel variants), %d frames (every render kernel of the loaded library + multi-view launches), 0 mismatches, seeds %s..%d" % (
+print("FUZZ OK: %d rounds, %d batch rays (3 kernel variants), %d frames (every render kernel of the loaded library + multi-view launches), 0 mismatches, seeds %s..%d" % (
     rounds, rays_checked, frames_checked, sys.argv[2] if len(sys.argv) > 2 else "1000", seed - 1), flush=True)

@@ -1,6 +1,7 @@
 // Debug harness: runs vxrt::trace_wave (one lane) and vxrt::trace_direct on the host against the C oracle.
 // build: g++ -O1 -g -std=c++17 -ffp-contract=off -Itests/tools/hoststub -Ioracle tests/tools/host_wave_check.cpp oracle/vxo_*.c -lm -lpthread
 #include "../voxelengine_amd/csrc/vxrt_wave.hpp"
+#include "../voxelengine_amd/csrc/vxrt_wave2.hpp"
 extern "C" {
 #include "vxo.h"
 }
@@ -37,13 +38,19 @@ int main(int argc, char** argv)
             const uint32_t t = ref_tiled_index(x, y, z, f / 8, f / 8), i = (uint32_t)hbm_index(x, y, z, f, f);
             if ((w->pool[s * bw + (t >> 5)] >> (t & 31)) & 1u) pool[s * bw + (i >> 5)] |= 1u << (i & 31);
         }
+    // the second tracer (vxrt_wave2.hpp) needs addressable slack around its tables: one x-z slice around the coarse bits,
+    // one brick around the pool (a lane that has just left the grid issues one more load)
+    const size_t cslack = (size_t)cx * cz / 32 + 1;
+    std::vector<uint32_t> coarse_pad(coarse.size() + 2 * cslack, 0xA5A5A5A5u), pool_pad(pool.size() + 2 * (size_t)bw, 0x5A5A5A5Au);
+    memcpy(coarse_pad.data() + cslack, coarse.data(), coarse.size() * 4);
+    memcpy(pool_pad.data() + bw, pool.data(), pool.size() * 4);
     WorldView W{};
-    W.coarse_bits = coarse.data(); W.cell_meta = meta.data(); W.pool = pool.data();
+    W.coarse_bits = coarse_pad.data() + cslack; W.cell_meta = meta.data(); W.pool = pool_pad.data() + bw;
     W.cx = cx; W.cy = cy; W.cz = cz; W.c_row = cx; W.c_slice = cx * cz;
     W.f = f; W.f_row = f; W.f_slice = f * f; W.brick_words = bw; W.ff = (float)f; W.inv_f = 1.0f / f;
     W.wmax_x = (float)((double)W.cx - 1e-6); W.wmax_y = (float)((double)W.cy - 1e-6); W.wmax_z = (float)((double)W.cz - 1e-6);
     W.X = S; W.Y = S;
-    int bad = 0;
+    int bad = 0, bad2 = 0;
     for (int i = 0; i < n; ++i) {
         float o[3], d[3];
         for (int a = 0; a < 3; ++a) { o[a] = (rand() / (float)RAND_MAX) * (i % 3 ? S : 3 * S) - (i % 3 ? 0 : S); d[a] = rand() / (float)RAND_MAX * 2 - 1; }
@@ -75,6 +82,17 @@ int main(int argc, char** argv)
         same2 = same2 && t3.hit == t.hit && t3.steps == t.steps && memcmp(&t3.normal, &t.normal, 12) == 0 && c3.coarse_probes == c.coarse_probes &&
                 c3.brick_entries == c.brick_entries && c3.fine_probes == c.fine_probes;
         if (t.hit) same2 = same2 && memcmp(&t3.pos, &t.pos, 12) == 0 && t3.vx == t.vx && t3.vy == t.vy && t3.vz == t.vz;
+        // the tracer built for the vector pipe's two instruction classes (vxrt_wave2.hpp): same results
+        if (tracer2_fits(W)) {
+            TraceResult t4{};
+            trace_wave2(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column);
+            bool s4 = t4.hit == t.hit && t4.steps == t.steps;
+            if (t.hit) s4 = s4 && memcmp(&t4.pos, &t.pos, 12) == 0 && memcmp(&t4.normal, &t.normal, 12) == 0 && t4.vx == t.vx && t4.vy == t.vy && t4.vz == t.vz;
+            if (!s4 && bad2++ < 5)
+                printf("tracer2: ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g): hit %d/%d steps %d/%d pos (%.9g,%.9g,%.9g)/(%.9g,%.9g,%.9g) vox (%d,%d,%d)/(%d,%d,%d)\n", i, o[0], o[1], o[2], d[0], d[1], d[2],
+                       t4.hit, t.hit, t4.steps, t.steps, t4.pos.x, t4.pos.y, t4.pos.z, t.pos.x, t.pos.y, t.pos.z, t4.vx, t4.vy, t4.vz, t.vx, t.vy, t.vz);
+            same2 = same2 && s4;
+        }
         bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries && c.fine_probes == st.fine_probes;
         if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
         ok = ok && same2;

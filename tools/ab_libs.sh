@@ -11,7 +11,7 @@ run() {
   [[ "$1" == *:* ]] && wpc=${1##*:}
   local lib=$R/voxelengine_amd/csrc/libvxrt.so
   [ "$tag" != base ] && lib=$R/voxelengine_amd/csrc/libvxrt_$tag.so
-  VXRT_LIB=$lib VXRT_WAVES_PER_CU=$wpc python3 $R/bench.py --cpu-baseline off ${BENCH_ARGS:-} > $OUT/$2.json 2> $OUT/$2.err || { echo "$1 failed"; tail -20 $OUT/$2.err; echo "stopping: no further GPU run behind a failed one (full log: $OUT/$2.err)"; exit 1; }
+  VXRT_LIB=$lib VXRT_WAVES_PER_CU=$wpc VXRT_SKIP_STALE_CHECK=1 python3 $R/bench.py --cpu-baseline off ${BENCH_ARGS:-} > $OUT/$2.json 2> $OUT/$2.err || { echo "$1 failed"; tail -20 $OUT/$2.err; echo "stopping: no further GPU run behind a failed one (full log: $OUT/$2.err)"; exit 1; }
   python3 - "$OUT/$2.json" "$1" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))

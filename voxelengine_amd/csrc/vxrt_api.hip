@@ -51,7 +51,9 @@ struct vxrt_ctx {
     // world
     bool has_world = false;
     vxrt::WorldView view{};
-    uint32_t* d_coarse = nullptr;
+    uint32_t* d_coarse = nullptr;   // (inside coarse_alloc, with slack before and behind: vxrt_wave2.hpp)
+    void* coarse_alloc = nullptr;
+    void* pool_alloc = nullptr;
     uint2* d_meta = nullptr;
     uint32_t* d_pool = nullptr;
     uint64_t ncells = 0, nslots = 0, pool_capacity_slots = 0;
@@ -102,9 +104,10 @@ void stream_drop(vxrt_ctx* c);  // defined with the chunk streaming code below
 static void free_world(vxrt_ctx* c)
 {
     stream_drop(c);
-    if (c->d_coarse) (void)hipFree(c->d_coarse);
+    if (c->coarse_alloc) (void)hipFree(c->coarse_alloc);
     if (c->d_meta) (void)hipFree(c->d_meta);
-    if (c->d_pool) (void)hipFree(c->d_pool);
+    if (c->pool_alloc) (void)hipFree(c->pool_alloc);
+    c->coarse_alloc = c->pool_alloc = nullptr;
     c->d_coarse = nullptr;
     c->d_meta = nullptr;
     c->d_pool = nullptr;
@@ -155,9 +158,18 @@ int alloc_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t pool_slots)
     free_world(c);
     c->ncells = (uint64_t)cd[0] * cd[1] * cd[2];
     uint64_t bw = (uint64_t)factor * factor * factor / 32;
-    VX_HIP(hipMalloc((void**)&c->d_coarse, ((c->ncells + 31) / 32) * sizeof(uint32_t)));
+    // The tracer of vxrt_wave2.hpp lets a lane that has just left the grid (or a brick) issue one more load, one x-z slice
+    // (one brick row-plane) beyond the table at most: both tables sit inside allocations with that much addressable slack
+    // before and behind them.  The slack is never written and its bits are never used.
+    const uint64_t coarse_bytes = ((c->ncells + 31) / 32) * sizeof(uint32_t);
+    const uint64_t coarse_slack = (((uint64_t)cd[0] * cd[2] / 8 + 64) + 255) / 256 * 256;
+    VX_HIP(hipMalloc(&c->coarse_alloc, coarse_bytes + 2 * coarse_slack));
+    c->d_coarse = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->coarse_alloc) + coarse_slack);
     VX_HIP(hipMalloc((void**)&c->d_meta, c->ncells * sizeof(uint2)));
-    VX_HIP(hipMalloc((void**)&c->d_pool, (pool_slots ? pool_slots : 1) * bw * sizeof(uint32_t)));
+    const uint64_t pool_bytes = (pool_slots ? pool_slots : 1) * bw * sizeof(uint32_t);
+    const uint64_t pool_slack = (bw * sizeof(uint32_t) + 255) / 256 * 256;
+    VX_HIP(hipMalloc(&c->pool_alloc, pool_bytes + 2 * pool_slack));
+    c->d_pool = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->pool_alloc) + pool_slack);
     c->pool_capacity_slots = pool_slots;
     return VXRT_OK;
 }
@@ -404,8 +416,8 @@ int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
     if (c && (variant == 0 || variant == 3))
         return fail(VXRT_ERR_INVALID, "render kernel variants 0 (wave state machine) and 3 (LDS pixel pool) are A/B kernels of the experiments build (make -C voxelengine_amd/csrc libvxrt_exp.so)");
 #endif
-    if (!c || variant < 0 || variant > 6)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default, picked per launch), 5 (persistent, cold state in LDS, 5 waves per SIMD) or 6 (traversal / shading kernels over ray queues)");
+    if (!c || variant < 0 || variant > 7)
+        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default, picked per launch), 5 (persistent, cold state in LDS, 5 waves per SIMD), 6 (traversal / shading kernels over ray queues) or 7 (variant 5 on the tracer of vxrt_wave2.hpp)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }

@@ -573,6 +573,46 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
 
 #include "vxrt_persist.hpp"
 #include "vxrt_persist_lds.hpp"
+#include "vxrt_persist2.hpp"
+
+namespace vxrt {
+
+// The batch query on the tracer of vxrt_wave2.hpp (kernel variant 7): one ray per lane, the tracer's cold fields in LDS.
+// It exists so that the batch tests and the randomised parity runs reach that tracer with caller-made rays.
+__global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
+{
+    __shared__ uint32_t cold_block[4][CF_TRACER_FIELDS * 64];
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < B.n;
+    const unsigned long long j = live ? i : 0ull;
+    f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
+    f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
+    TraceResult t;
+    t.hit = false;
+    t.steps = 0;
+    t.pos = t.normal = mk3(0, 0, 0);
+    t.vx = t.vy = t.vz = 0;
+    t.ncode = 0u;
+    trace_wave2(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63]);
+    if (live) {
+        f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
+        B.pos[3 * i] = p.x;
+        B.pos[3 * i + 1] = p.y;
+        B.pos[3 * i + 2] = p.z;
+        B.normal[3 * i] = t.normal.x;
+        B.normal[3 * i + 1] = t.normal.y;
+        B.normal[3 * i + 2] = t.normal.z;
+        B.steps[i] = t.steps;
+        if (B.hit)
+            B.hit[i] = t.hit ? 1 : 0;
+        if (B.voxel)
+            B.voxel[i] = t.hit ? (long long)t.vx + (long long)B.W.X * ((long long)t.vy + (long long)B.W.Y * (long long)t.vz)
+                               : -1ll;
+    }
+}
+
+}  // namespace vxrt
+
 #ifdef VXRT_EXPERIMENTS
 #include "vxrt_pool.hpp"  // variant 3: A/B builds only
 #endif
@@ -658,6 +698,8 @@ int resolve_render_variant(const RenderArgs& A, int variant)
     if (variant == 0 || variant == 3)
         variant = 2;  // (not in this build; vxrt_set_kernel_variant refuses them)
 #endif
+    if (variant == 7 && !tracer2_fits(A.W))
+        variant = 5;  // (vxrt_wave2.hpp packs the steps left to the grid's faces into 11 + 10 + 11 bits)
     if (variant == 6) {  // the wavefront pipeline indexes pixels and queue slots with 32 bits and keeps a queue per generation
         const unsigned long long nv = A.nviews ? A.nviews : 1u;
         const unsigned long long slots = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * 64ull * nv;
@@ -691,11 +733,20 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             return launch_render_ts(A, *ts, stats, stream);
         variant = 5;  // (no workspace was leased: cannot happen through vxrt_api.hip)
     }
-    if (variant == 2 || variant == 3 || variant == 5) {
+    if (variant == 7 && stats) {
+#ifdef VXRT_EXPERIMENTS
+        static const bool diag2 = getenv("VXRT_DIAG2") != nullptr;  // loop diagnostics of the variant-7 kernel itself
+        if (!diag2)
+#endif
+            variant = 5;  // the tracer of vxrt_wave2.hpp counts no probes: the counting launch runs the round-2 kernel
+    }
+    if (variant == 2 || variant == 3 || variant == 5 || variant == 7) {
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
         // persistent_waves = 4 per SIMD; variant 5's kernel is built for VXRT_PERSIST_LDS_OCC
-        const unsigned resident = std::max(1u, variant == 5 ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST_LDS_OCC : A.persistent_waves);
+        const unsigned resident = std::max(1u, variant == 5   ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST_LDS_OCC
+                                               : variant == 7 ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST2_OCC
+                                                              : A.persistent_waves);
         const unsigned waves = ntiles < resident ? (unsigned)ntiles : resident;
         const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
@@ -713,6 +764,8 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             VXRT_LAUNCH_POOL(S, B2, M);                                                      \
         else if (variant == 5)                                                               \
             hipLaunchKernelGGL((k_render_persist_lds<S, B2, M>), g, b, 0, stream, A);        \
+        else if (variant == 7)                                                               \
+            hipLaunchKernelGGL((k_render_persist2<S, B2, M>), g, b, 0, stream, A);           \
         else                                                                                 \
             hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A);          \
     } while (0)
@@ -756,6 +809,10 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
     // default: persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the
     // persistent grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
+    if (variant == 7 && !stats && !B.dbg_trace && tracer2_fits(B.W)) {
+        hipLaunchKernelGGL(k_trace_batch_wave2, grid, block, 0, stream, B);
+        return hipSuccess;
+    }
     if (variant >= 2 && B.ticket && !B.dbg_trace  // (render variants 3..5 are all 'persistent' for a batch)
          && B.persistent_waves && B.n >= 8ull * 64ull * B.persistent_waves) {
         const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);

@@ -42,9 +42,12 @@ __device__ __forceinline__ f3 normal_decode(uint32_t c)
 #ifndef VXRT_VOTE_NUM
 #define VXRT_VOTE_NUM 4
 #endif
+#ifndef VXRT_VOTE_DEN
+#define VXRT_VOTE_DEN 1  // A/B knob: parked * num >= others * den
+#endif
 __device__ __forceinline__ bool vote_run(int parked, int others, int num = VXRT_VOTE_NUM)
 {
-    return parked > 0 && parked * num >= others;
+    return parked > 0 && parked * num >= others * VXRT_VOTE_DEN;
 }
 // Per-phase thresholds, from a sweep on the bench workload: the expensive phases (ray finished ~450 VALU, end of
 // walk ~130) wait until their lanes are a third of the live ones, the cheap tight-box test (~60) runs at a fifth.

@@ -1,0 +1,648 @@
+// vxrt_wave2.hpp -- the two-level brickmap DDA of vxrt_wave.hpp re-designed for what a gfx950 SIMD actually issues.
+//
+// profiles/r03_instr_cost.md: the render kernels are bound by the vector ALU pipe, and its instructions come in two
+// classes -- ~2.3 cycles per wave64 instruction (add / sub / mul f32, and / or / xor, add / sub u32, right shifts, moves,
+// with vector or constant operands) and ~4.15 cycles (every compare, v_cndmask, min / max, conversions, every
+// three-operand form, anything with a scalar-register operand) -- beside a scalar pipe with one instruction per ~4.15
+// cycles.  WaveTracer::step2 is 71 slow + 34 fast vector instructions per probe pair (373 cycles).  This tracer keeps the
+// same results (Raytrace / DDARayTraversal, VoxelRT/VolumeRaytracer.cu:176-525) with a probe made for that machine:
+//
+//  * The DDA advance is SPECULATIVE and exec-masked.  A DDA's path does not depend on the voxels, only where it stops
+//    does; so every walking lane advances in every probe, before its occupancy word has arrived, and the word only
+//    decides who stops.  The advance is committed in place under the wave masks of the three axes
+//    (`s_mov_b64 exec, mask` on the scalar pipe + fast vector instructions) instead of add + v_cndmask per quantity.
+//    A lane that stops has the state before its last advance in a two-deep history (rp / rpp, tp), so nothing is undone.
+//  * The cell is not kept as three integers that are clamped (3 v_med3), range-checked (3 v_cmp) and multiplied into a
+//    bit index (2 v_mad) per probe.  The probe carries the BIT INDEX itself, advanced by the axis' stride, and the
+//    remaining steps to the grid's faces as three counters packed in one word with a guard bit each (`rem`): one
+//    subtraction per advance, one and + one compare per probe to see any of the three run out.  The cell coordinates,
+//    the step count (stepsTaken) and the last step's axis are decoded from rem and its history when a walk ends.
+//  * The crossing point, the [0,f]^3 region check on it (:325-341) and HitIntersectedPoint are not evaluated per probe.
+//    cross(t) = start + t * d is monotone in t, so the check can only fail before a time t_lo or after a time t_hi that
+//    begin_walk computes with a relative margin; the probe compares t with t_hi (one compare), a lane beyond it -- or
+//    leaving the grid, which is later than t_hi by construction -- ends its walk, and the end-of-walk phase evaluates the
+//    reference's expressions on that one step exactly (and puts a lane that passes back on its walk).  The point is
+//    recomputed there from the step's t and axis.
+//  * Lane state that the probe tests lives in wave masks (scalar registers): brick / coarse level.  Everything rare is
+//    pushed to "single-step mode" (t_hi = -inf: every step is validated by the end-of-walk phase, which then also
+//    recomputes the bit index from the cell): edge-rule starts on several far faces at once, starts whose first crossing
+//    may fail the region check.  The common edge-rule start (one far face, stepped first) costs one subtraction per pair.
+//
+// Limits (tracer2_fits; the launch policy keeps the round-2 kernels otherwise): coarse dimensions x, z <= 1022 and
+// y <= 510 cells (rem's fields), and a walk cannot run into MAX_STEPS (cx + cy + cz + 4 < 2048), so stepsTaken needs no
+// counter.  The world's tables need addressable slack of one x-z slice before and behind the coarse bits and of one
+// brick around the pool (vxrt_api.hip allocates it): a lane that has just left the grid issues one more load.
+#pragma once
+
+#include "vxrt_wave.hpp"
+#ifdef VXRT_HOST_DEBUG
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace vxrt {
+
+enum : uint32_t { ST_ENDHIT = 5u };  // walk ended on an occupied voxel / an occupied coarse cell whose tight box was hit
+
+constexpr uint32_t kRemDecX = 1u, kRemDecY = 1u << 11, kRemDecZ = 1u << 21;
+constexpr uint32_t kRemGuards = (1u << 10) | (1u << 20) | (1u << 31);
+constexpr float kThrEps = 9.5367431640625e-07f;  // 2^-20: relative margin of the region-check thresholds
+constexpr float kMinFastDir = 9.094947017729282e-13f;  // 2^-40: smallest direction component begin_walk_fast divides by
+
+__host__ __device__ inline bool tracer2_fits(const WorldView& W)
+{
+    return W.cx <= 1022 && W.cz <= 1022 && W.cy <= 510 && W.f <= 32 && W.cx + W.cy + W.cz + 4 < kMaxSteps;
+}
+
+__device__ __forceinline__ uint32_t rem_fx(uint32_t r) { return r & 0x7FFu; }
+__device__ __forceinline__ uint32_t rem_fy(uint32_t r) { return (r >> 11) & 0x3FFu; }
+__device__ __forceinline__ uint32_t rem_fz(uint32_t r) { return r >> 21; }
+__device__ __forceinline__ uint32_t rem_sum(uint32_t r) { return rem_fx(r) + rem_fy(r) + rem_fz(r); }
+
+struct WaveTracer2 {
+    // per ray
+    f3 d;
+    float ivx, ivy, ivz;  // 1/(d or eps) (:127-129); |iv| is the DDA's tDelta (:199-201)
+    // current walk, read by the probes
+    float tn_x, tn_y, tn_z;
+    uint32_t idx;             // bit index of the (clamped) current cell + the level's bias (one x-z slice)
+    uint32_t di_x, di_y, di_z;  // what one step along the axis adds to idx
+    uint32_t rem, rp, rpp;    // steps left to the faces, packed (x | y << 11 | z << 21, one guard bit per field); history
+    float tl, tp;             // t of the last advance and of the one before
+    float t_hi;               // the probe ends the walk of a lane whose t exceeds it (-inf: single-step mode)
+    uint32_t fix;             // edge rule: the first step along the axis that starts on its far face does not move idx
+    const uint32_t* bits;     // the level's words - bias
+    uint32_t st;
+    // current walk, read by the phases only
+    f3 ws;
+    uint32_t rem0;            // sum of rem's fields at the start of the walk
+    float t_hi_real;
+    bool special;             // per ray: a direction component is zero or below 2^-40
+    uint32_t dn;              // per ray: bit k set where the ray does not move up axis k (d_k <= 0)
+    f3 point;                 // HitIntersectedPoint of the walk that ended (tight-box phase / end-of-walk phase)
+    lanemask_t fine_m;        // wave mask: lanes walking inside a brick
+    uint32_t* cold;           // &block[lane]; field F of this lane is cold[F * 64] (CF_* of vxrt_wave.hpp)
+
+    __device__ __forceinline__ bool lane_fine() const
+    {
+#ifdef VXRT_HOST_CHECK
+        return (fine_m & 1ull) != 0ull;
+#else
+        return lane_test(fine_m);
+#endif
+    }
+
+    __device__ __forceinline__ void init(const WorldView& W, uint32_t* cold_column)
+    {
+        cold = cold_column;
+        st = ST_DONE;
+        d = mk3(1.0f, 0.0f, 0.0f);
+        ivx = ivy = ivz = 1.0f;
+        tn_x = tn_y = tn_z = 0.0f;
+        idx = (uint32_t)W.c_slice;
+        di_x = di_y = di_z = 0u;
+        rem = rp = rpp = 0u;
+        tl = tp = 0.0f;
+        t_hi = t_hi_real = kInf;
+        special = false;
+        dn = 6u;
+        fix = 0u;
+        bits = W.coarse_bits - (W.c_slice >> 5);
+        ws = point = mk3(0, 0, 0);
+        rem0 = 0u;
+        fine_m = 0ull;
+    }
+
+    // slab test against [bmin,bmax] from point s with the hoisted reciprocals (RayIntersectsAABB, :124-174)
+    __device__ __forceinline__ bool slab(f3 s, f3 bmin, f3 bmax, f3& p, uint32_t& code) const
+    {
+        float ax = (bmin.x - s.x) * ivx, bx = (bmax.x - s.x) * ivx;
+        float ay = (bmin.y - s.y) * ivy, by = (bmax.y - s.y) * ivy;
+        float az = (bmin.z - s.z) * ivz, bz = (bmax.z - s.z) * ivz;
+        float nx = lo(ax, bx), fx = hi(ax, bx);
+        float ny = lo(ay, by), fy = hi(ay, by);
+        float nz = lo(az, bz), fz = hi(az, bz);
+        float t_in = hi(hi(nx, ny), nz);
+        float t_out = lo(lo(fx, fy), fz);
+        p = mk3(s.x + t_in * d.x, s.y + t_in * d.y, s.z + t_in * d.z);
+        code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
+                            : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
+        return !(t_out < hi(t_in, 0.0f));
+    }
+
+    // cell coordinates (unclamped) of a rem word of the current walk
+    __device__ __forceinline__ void cells_of(const WorldView& W, bool fine, uint32_t r, int& x, int& y, int& z) const
+    {
+        const int dmx = fine ? W.f : W.cx, dmy = fine ? W.f : W.cy, dmz = fine ? W.f : W.cz;
+        const int fx = (int)rem_fx(r), fy = (int)rem_fy(r), fz = (int)rem_fz(r);
+        x = d.x > 0 ? dmx - 1 - fx : fx;  // (an axis that moves up never starts on its far face: no pad)
+        y = d.y > 0 ? dmy - 1 - fy : fy;
+        z = d.z > 0 ? dmz - 1 - fz : fz;
+    }
+
+    // x / dv for a direction component of ordinary size, with iv = RN(1 / dv): q = RN(x * iv), then one correction with
+    // the exact residual, q' = RN(q + (x - q * dv) * iv).  With a correctly rounded reciprocal that is the correctly
+    // rounded quotient (Markstein); checked against the division on 7e8 operand pairs of this code's ranges, the all-ones
+    // significands included.  (x is a difference of two floats here: never -0, the one operand the form gets wrong.)
+    static __device__ __forceinline__ float fast_div(float x, float dv, float iv)
+    {
+        const float q = x * iv;
+        return fmaf(fmaf(-q, dv, x), iv, q);
+    }
+
+    // DDARayTraversal's set-up (:178-232) for a walk from s on the level FINE, written for the vector pipe's two
+    // instruction classes: sign masks and integer arithmetic instead of compare + select, the three quotients by fast_div,
+    // no entry-side threshold (a start outside [0, f] begins in single-step mode and leaves it with the first validated
+    // step whose three components are inside: walk_on).  Sets st: ST_WALK, or ST_END for a start outside the grid (the
+    // first iteration of the reference leaves at once: no step, isOutOfBounds).  The caller updates fine_m.
+    // Rays with a direction component that is zero or below 2^-40 (`special`: the centre column of an axis-aligned
+    // camera, adversarial tests) get their quotients from the division itself and validate every step of a brick walk.
+    template <bool FINE>
+    __device__ __forceinline__ void start_walk(const WorldView& W, const f3 s)
+    {
+        ws = s;
+        const int dmx = FINE ? W.f : W.cx, dmy = FINE ? W.f : W.cy, dmz = FINE ? W.f : W.cz;
+        const uint32_t row = (uint32_t)(FINE ? W.f_row : W.c_row), slice = (uint32_t)(FINE ? W.f_slice : W.c_slice);
+        // n = all ones where the ray does not move up the axis (d <= 0), m = all ones where it moves up (:195-197)
+        const uint32_t nx = 0u - (dn & 1u), ny = 0u - ((dn >> 1) & 1u), nz = 0u - (dn >> 2);
+        const uint32_t mx = ~nx, my = ~ny, mz = ~nz;
+        const int c_x = f2i(s.x), c_y = f2i(s.y), c_z = f2i(s.z);
+        const float xx = (float)(c_x + (int)(nx + 1u)) - s.x, xy = (float)(c_y + (int)(ny + 1u)) - s.y,
+                    xz = (float)(c_z + (int)(nz + 1u)) - s.z;
+        tn_x = fast_div(xx, d.x, ivx);
+        tn_y = fast_div(xy, d.y, ivy);
+        tn_z = fast_div(xz, d.z, ivz);
+        bool zero_on_face = false;  // an axis the ray does not move along starts on its far face: no pad there (d < 0 only)
+        if (__ballot(special) != 0ull) {
+            if (special) {
+                tn_x = d.x != 0 ? xx / d.x : kInf;
+                tn_y = d.y != 0 ? xy / d.y : kInf;
+                tn_z = d.z != 0 ? xz / d.z : kInf;
+                zero_on_face = (d.x == 0 && c_x == dmx) || (d.y == 0 && c_y == dmy) || (d.z == 0 && c_z == dmz);
+            }
+        }
+        // steps left to the face: up: dim - 1 - cell = (cell ^ ~0) + dim; down: cell
+        const uint32_t fx = ((uint32_t)c_x ^ mx) + (mx & (uint32_t)dmx), fy = ((uint32_t)c_y ^ my) + (my & (uint32_t)dmy),
+                       fz = ((uint32_t)c_z ^ mz) + (mz & (uint32_t)dmz);
+        // inside: up: 0 <= f <= dim - 1; down: 0 <= f <= dim (f == dim only under the edge rule, which it then switches on,
+        // :216-232)
+        const bool inside = fx < (uint32_t)dmx - nx && fy < (uint32_t)dmy - ny && fz < (uint32_t)dmz - nz && !zero_on_face;
+        rem = rp = rpp = inside ? (fx | (fy << 11) | (fz << 21)) : 0u;
+        rem0 = inside ? fx + fy + fz : 0u;
+        // lookups use the cell clamped to dim-1 (:242-244; differs from the cell only on a far face under the edge rule)
+        const int q_x = clamp_cell(c_x, dmx - 1), q_y = clamp_cell(c_y, dmy - 1), q_z = clamp_cell(c_z, dmz - 1);
+        idx = cell_index(q_x, q_y, q_z, (int)row, (int)slice) + slice;
+        di_x = nx | 1u;
+        di_z = (row ^ nz) - nz;
+        di_y = (slice ^ ny) - ny;
+        // Edge rule: an axis that starts ON its far face (cell == dim; inside: such an axis moves down) takes one step that
+        // does not change the clamped cell.  If there is one such axis and it is the DDA's first choice, the probes handle
+        // it (idx gets `fix` subtracted after the first advance); anything else goes to single-step mode.
+        const uint32_t ex = (uint32_t)(c_x - q_x), ey = (uint32_t)(c_y - q_y), ez = (uint32_t)(c_z - q_z);
+        bool single = FINE && special;
+        fix = 0u;
+        if (__ballot(inside && (ex | ey | ez) != 0u) != 0ull) {
+            const bool a0 = tn_x < tn_y && tn_x < tn_z;
+            const bool a1 = !(tn_x < tn_y) && tn_y < tn_z;
+            const bool a2 = !a0 && !a1;
+            const uint32_t npend = ex + ey + ez;
+            const bool simple = npend == 1u && ((ex != 0u && a0) || (ey != 0u && a1) || (ez != 0u && a2));
+            fix = simple ? (((0u - ex) & di_x) | ((0u - ey) & di_y) | ((0u - ez) & di_z)) : 0u;
+            single = single || (npend != 0u && !simple);
+        }
+        float hi_t = kInf;
+        if (FINE) {
+            // Region check of a brick walk (:325-341): component k of the crossing point, start_k + (t * d_k), is monotone
+            // in t; on its exit side it stays inside until t = (bound_k - s_k) / d_k, bound = f (up) or 0.  The threshold
+            // carries a relative margin of 2^-20 towards the inside, far more than the two roundings of the expression can
+            // move it.  A step along k itself is not checked against k's own bound by the reference, but a step that is
+            // later than this along another axis is rare enough (the lane is within 1e-6 of leaving through k) to be
+            // validated one by one.
+            const uint32_t Fb = __float_as_uint(W.ff);
+            const float hx = (__uint_as_float(Fb & mx) - s.x) * ivx, hy = (__uint_as_float(Fb & my) - s.y) * ivy,
+                        hz = (__uint_as_float(Fb & mz) - s.z) * ivz;
+            hi_t = fminf(fminf(hx, hy), hz);
+            hi_t = hi_t - fabsf(hi_t) * kThrEps;
+            hi_t = special ? -kInf : hi_t;
+            // entry side: a start outside [0, f] on some axis (sign bit of s_k or of f - s_k)
+            const uint32_t out = __float_as_uint(s.x) | __float_as_uint(s.y) | __float_as_uint(s.z) | __float_as_uint(W.ff - s.x) |
+                                 __float_as_uint(W.ff - s.y) | __float_as_uint(W.ff - s.z);
+            single = single || (int32_t)out < 0;
+        }
+        t_hi_real = hi_t;
+        t_hi = single ? -kInf : hi_t;
+        if (!FINE)
+            bits = W.coarse_bits - (slice >> 5);  // (brick walks: the caller has set the brick's words)
+        st = inside ? (uint32_t)ST_WALK : (uint32_t)ST_END;
+    }
+
+    // Raytrace's prologue (:359-384): per-ray constants, world entry, first coarse walk.  Per lane; the caller clears the
+    // lanes' bits in fine_m afterwards (after_begin_ray), where the wave is converged again.
+    __device__ __forceinline__ void begin_ray(const WorldView& W, f3 origin, f3 ray, int max_steps_)
+    {
+        d = unit3(ray);
+        ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // :127-129
+        ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
+        ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
+        f3 s0 = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
+        uint32_t ec = 0u;
+        if (!(s0.x >= 0 && s0.y >= 0 && s0.z >= 0 && s0.x < (float)W.cx && s0.y < (float)W.cy && s0.z < (float)W.cz)) {
+            const float e = (float)1e-6;
+            f3 p;
+            uint32_t c;
+            if (slab(s0, mk3(e, e, e), mk3(W.wmax_x, W.wmax_y, W.wmax_z), p, c)) {
+                s0 = p;
+                ec = c;
+            }
+        }
+        cold[CF_RAY_CODES * 64] = ec | ((uint32_t)max_steps_ << 7);  // out_code = 0, ray_hit = false
+        cold[CF_START_X * 64] = __float_as_uint(s0.x);
+        cold[CF_START_Y * 64] = __float_as_uint(s0.y);
+        cold[CF_START_Z * 64] = __float_as_uint(s0.z);
+        cold[CF_LAST_CI * 64] = 0xFFFFFFFFu;  // previous_cell as its cell index (unique per cell); none yet
+        cold[CF_TOTAL * 64] = 0u;
+        special = !(fabsf(d.x) >= kMinFastDir && fabsf(d.y) >= kMinFastDir && fabsf(d.z) >= kMinFastDir);
+        dn = (d.x > 0 ? 0u : 1u) | (d.y > 0 ? 0u : 2u) | (d.z > 0 ? 0u : 4u);
+        start_walk<false>(W, s0);
+    }
+    __device__ __forceinline__ void after_begin_ray(bool launched) { fine_m &= ~__ballot(launched); }
+
+    // The crossing point of the step that started from rem word `before` (the cell before the step) along the axis
+    // whose field the step decremented by `dec`, at time t -- the reference's `cross` (:293-313).
+    __device__ __forceinline__ f3 cross_of(const WorldView& W, bool fine, uint32_t before, uint32_t dec, float t) const
+    {
+        int bx, by, bz;
+        cells_of(W, fine, before, bx, by, bz);
+        const bool on_x = dec == kRemDecX, on_y = dec == kRemDecY, on_z = dec == kRemDecZ;
+        return mk3(on_x ? (float)(bx + (d.x > 0 ? 1 : 0)) : ws.x + (t * d.x), on_y ? (float)(by + (d.y > 0 ? 1 : 0)) : ws.y + (t * d.y),
+                   on_z ? (float)(bz + (d.z > 0 ? 1 : 0)) : ws.z + (t * d.z));
+    }
+
+    // A lane goes back to its walk after a phase (a suspected step that passed its checks, a tight box that was missed).
+    // Single-step mode recomputes idx from the cell (edge rule: the clamped cell), and ends once no axis is on its far
+    // face any more and the crossing point just validated has all three components inside [0, f] (from there on only
+    // the exit side of the region check can fail, which t_hi watches).
+    __device__ __forceinline__ void walk_on(const WorldView& W, bool is_fine, bool lin_inside)
+    {
+        const bool single = t_hi == -kInf;
+        int x, y, z;
+        cells_of(W, is_fine, rem, x, y, z);
+        const int dmx = is_fine ? W.f : W.cx, dmy = is_fine ? W.f : W.cy, dmz = is_fine ? W.f : W.cz;
+        const int row = is_fine ? W.f_row : W.c_row, slice = is_fine ? W.f_slice : W.c_slice;
+        const uint32_t exact = cell_index(min(x, dmx - 1), min(y, dmy - 1), min(z, dmz - 1), row, slice) + (uint32_t)slice;
+        idx = single ? exact : idx;
+        const bool pending = x == dmx || y == dmy || z == dmz;
+        t_hi = (single && !pending && lin_inside) ? t_hi_real : t_hi;
+    }
+
+    // parked phase: end of a walk (:395-511).  Called by the whole wave (converged); works on the lanes with st == ST_END
+    // (the last advance left the grid and / or was later than t_hi, or the walk never started) and ST_ENDHIT (a brick walk
+    // whose probe found an occupied voxel).  Coarse walks that end on a hit tight box never come here: the tight-box
+    // phase enters the brick itself.
+    __device__ __forceinline__ void phase_end(const WorldView& W)
+    {
+        const bool me = st == ST_END || st == ST_ENDHIT;
+        const bool is_fine = lane_fine();
+        bool go_coarse = false;  // this lane restarts the coarse walk
+        if (me) {
+            // ---- what the walk that just ended did.  ST_ENDHIT: the probe of the cell `rp` found it occupied; the advance
+            // after it (rp -> rem) is the reference's exit advance.  ST_END: validate the last advance (rp -> rem, at time
+            // tl) with the reference's expressions.
+            const bool hit = st == ST_ENDHIT;
+            const uint32_t dec_last = rp - rem, dec_prev = rpp - rp;
+            const bool stepped = dec_last != 0u;
+            const bool exiting = (rem & kRemGuards) != 0u || !stepped;
+            const float F = W.ff;
+            const f3 lin = mk3(ws.x + (tl * d.x), ws.y + (tl * d.y), ws.z + (tl * d.z));
+            int bx, by, bz;
+            cells_of(W, is_fine, rp, bx, by, bz);
+            const f3 cr = mk3(dec_last == kRemDecX ? (float)(bx + (d.x > 0 ? 1 : 0)) : lin.x,
+                              dec_last == kRemDecY ? (float)(by + (d.y > 0 ? 1 : 0)) : lin.y,
+                              dec_last == kRemDecZ ? (float)(bz + (d.z > 0 ? 1 : 0)) : lin.z);
+            const bool region_fail = is_fine && stepped &&
+                                     (cr.x < 0.0f || cr.x > F || cr.y < 0.0f || cr.y > F || cr.z < 0.0f || cr.z > F);
+            const bool resume = !hit && !exiting && !region_fail;  // a step that was only suspected: walk on
+            if (resume) {
+                const bool lin_inside = !(lin.x < 0.0f || lin.x > F || lin.y < 0.0f || lin.y > F || lin.z < 0.0f || lin.z > F);
+                walk_on(W, is_fine, lin_inside);
+                st = ST_WALK;
+            } else {
+                // steps counted by this walk, and its last counted step
+                const bool last_counts = !hit && stepped && !region_fail;
+                const uint32_t steps = rem0 - rem_sum(rp) + (last_counts ? 1u : 0u);
+                const uint32_t dec_c = last_counts ? dec_last : dec_prev;  // the last counted step's axis
+                f3 pc = cr;
+                if (!last_counts)
+                    pc = cross_of(W, is_fine, rpp, dec_prev, tp);
+                point.x = steps != 0u ? pc.x : ws.x;
+                point.y = steps != 0u ? pc.y : ws.y;
+                point.z = steps != 0u ? pc.z : ws.z;
+                // ---- Raytrace's loop body after the walk (:395-511)
+                const int total_ = (int)cold[CF_TOTAL * 64] + (int)steps;
+                cold[CF_TOTAL * 64] = (uint32_t)total_;
+                if (hit) {  // :493-506 (brick walks only)
+                    const uint32_t box_codes = cold[CF_BOX_CODES * 64];
+                    const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
+                    // normal code of the hit = (axis + 1) | 4 * negative of the last counted step; the coarse hit's if none
+                    const uint32_t axis1 = dec_c == kRemDecX ? 1u : (dec_c == kRemDecY ? 2u : 3u);
+                    const bool up_last = dec_c == kRemDecX ? d.x > 0 : (dec_c == kRemDecY ? d.y > 0 : d.z > 0);
+                    const uint32_t hit_code = steps == 0u ? (box_codes & 7u) : (axis1 + (up_last ? 0u : 4u));
+                    cold[CF_RAY_CODES * 64] = (ray_codes & ~0x78u) | (hit_code << 3) | 0x40u;
+                    st = ST_DONE;
+                } else if (!is_fine) {
+                    st = ST_DONE;  // the coarse walk left the world (:399-401)
+                } else {
+                    // brick miss (:431-491): start = hitPosition / f; if start is still inside HitCell, nudge all three
+                    // components one ulp along the ray, and if that is not enough snap one axis to NextCell
+                    const int hx = (int)cold[CF_CHX * 64], hy = (int)cold[CF_CHY * 64], hz = (int)cold[CF_CHZ * 64];
+                    const float fx = (float)hx, fy = (float)hy, fz = (float)hz;
+                    const f3 hp = mk3(point.x + fx * W.ff, point.y + fy * W.ff, point.z + fz * W.ff);  // :426
+                    float sx = hp.x * W.inv_f, sy = hp.y * W.inv_f, sz = hp.z * W.inv_f;
+                    const bool nudge = trunc_equals(sx, fx) & trunc_equals(sy, fy) & trunc_equals(sz, fz);  // :441-444
+                    if (__ballot(nudge) != 0ull) {
+                        const float ux = ulp_step(sx, d.x < 0), uy = ulp_step(sy, d.y < 0), uz = ulp_step(sz, d.z < 0);
+                        sx = nudge ? ux : sx;
+                        sy = nudge ? uy : sy;
+                        sz = nudge ? uz : sz;
+                        const bool snap = nudge & trunc_equals(sx, fx) & trunc_equals(sy, fy) & trunc_equals(sz, fz);
+                        if (snap) {
+                            // NextCell (:347) = the UNCLAMPED coarse cell after the exit advance; it differs from the clamped
+                            // HitCell by one when the walk started on a far face (edge rule)
+                            const int nca = (int)(cold[CF_BOX_CODES * 64] >> 3);
+                            const int axis = nca & 3;
+                            const int ncx = hx + ((nca >> 2) & 1) + (axis == 0 ? (d.x > 0 ? 1 : -1) : 0);
+                            const int ncy = hy + ((nca >> 3) & 1) + (axis == 1 ? (d.y > 0 ? 1 : -1) : 0);
+                            const int ncz = hz + ((nca >> 4) & 1) + (axis == 2 ? (d.z > 0 ? 1 : -1) : 0);
+                            const float gx = (float)ncx - sx, gy = (float)ncy - sy, gz = (float)ncz - sz;
+                            const float mx = fabsf(gx), my = fabsf(gy), mz = fabsf(gz);
+                            const bool snap_x = (mx < my) & (mx < mz);               // :475-486, in the reference's order
+                            const bool snap_y = !snap_x & (my < mx) & (my < mz);
+                            const bool snap_z = !snap_x & !snap_y;
+                            sx = snap_x ? sx + gx : sx;
+                            sy = snap_y ? sy + gy : sy;
+                            sz = snap_z ? sz + gz : sz;
+                        }
+                    }
+                    cold[CF_START_X * 64] = __float_as_uint(sx);
+                    cold[CF_START_Y * 64] = __float_as_uint(sy);
+                    cold[CF_START_Z * 64] = __float_as_uint(sz);
+                    const bool restart = total_ < (int)(cold[CF_RAY_CODES * 64] >> 7);  // the while condition (:386)
+                    if (restart) {
+                        start_walk<false>(W, mk3(sx, sy, sz));
+                        go_coarse = true;
+                    } else {
+                        st = ST_DONE;
+                    }
+                }
+            }
+        }
+        // the level mask, where the wave is converged again
+        fine_m &= ~__ballot(go_coarse);
+    }
+
+    // parked phase: tight-box test of an occupied coarse cell (:248-273) and, on a hit, the end of the coarse walk with
+    // the entry into the cell's brick (:395-429).  Called by the whole wave; works on st == ST_BOX.
+    __device__ __forceinline__ void phase_box(const WorldView& W)
+    {
+        bool go_fine = false;
+        if (st == ST_BOX) {
+            int x, y, z;
+            cells_of(W, false, rp, x, y, z);  // the cell the probe found occupied
+            const int qx = min(x, W.cx - 1), qy = min(y, W.cy - 1), qz = min(z, W.cz - 1);
+            const uint32_t ci = cell_index(qx, qy, qz, W.c_row, W.c_slice);
+            const uint2 meta = W.cell_meta[ci];
+            const uint32_t e = meta.y;
+            const float fqx = (float)qx, fqy = (float)qy, fqz = (float)qz;
+            f3 bmin = mk3(((float)(e & 31u) + 0) * W.inv_f + fqx, ((float)((e >> 5) & 31u) + 0) * W.inv_f + fqy,
+                          ((float)((e >> 10) & 31u) + 0) * W.inv_f + fqz);
+            f3 bmax = mk3(((float)((e >> 15) & 31u) + 1) * W.inv_f + fqx, ((float)((e >> 20) & 31u) + 1) * W.inv_f + fqy,
+                          ((float)((e >> 25) & 31u) + 1) * W.inv_f + fqz);
+            f3 bp;
+            uint32_t bc;
+            const bool box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
+            if (box_hit) {
+                // the coarse walk ends here (:395-407): its steps, its HitIntersectedPoint (`step != 0`, :266)
+                const uint32_t steps = rem0 - rem_sum(rp);
+                cold[CF_TOTAL * 64] += steps;
+                point.x = steps != 0u ? bp.x : ws.x;
+                point.y = steps != 0u ? bp.y : ws.y;
+                point.z = steps != 0u ? bp.z : ws.z;
+                const bool enter = ci != cold[CF_LAST_CI * 64];  // not the previous_cell (:402-407)
+                if (enter) {
+                    // the exit iteration's extra advance (:290-322) only matters through NextCell: its axis (bits 0-1) and,
+                    // per axis, whether the unclamped cell sits one past the clamped HitCell (bits 2-4; edge rule only)
+                    const uint32_t dec = rp - rem;
+                    const int axis = dec == kRemDecX ? 0 : (dec == kRemDecY ? 1 : 2);
+                    const int packed = axis | ((x - qx) << 2) | ((y - qy) << 3) | ((z - qz) << 4);
+                    cold[CF_LAST_CI * 64] = ci;
+                    cold[CF_CHX * 64] = (uint32_t)qx;
+                    cold[CF_CHY * 64] = (uint32_t)qy;
+                    cold[CF_CHZ * 64] = (uint32_t)qz;
+                    cold[CF_BOX_CODES * 64] = bc | ((uint32_t)packed << 3);
+                    // hitPosition = point * f, the brick walk starts at hitPosition - HitCell * f (:397, :409-411)
+                    const f3 hp = mk3(point.x * W.ff, point.y * W.ff, point.z * W.ff);
+                    const f3 ns = mk3(hp.x - fqx * W.ff, hp.y - fqy * W.ff, hp.z - fqz * W.ff);
+                    bits = W.pool + (size_t)meta.x * W.brick_words - (W.f_slice >> 5);
+                    start_walk<true>(W, ns);
+                    go_fine = true;
+                } else {
+                    st = ST_DONE;
+                }
+            } else {
+                // not a hit: the advance the probe made stands; it may have left the world
+                const bool left = (rem & kRemGuards) != 0u;
+                if (!left)
+                    walk_on(W, false, true);
+                st = left ? (uint32_t)ST_END : (uint32_t)ST_WALK;
+            }
+        }
+        fine_m |= __ballot(go_fine);
+    }
+
+    // Two probes.  Per probe: load the occupancy word of idx; advance every walking lane (history, t, then tn / idx / rem
+    // of the chosen axis under that axis' mask); see who left the grid or passed t_hi; when the word arrives, see who
+    // stood on an occupied cell.  The second probe's address does not depend on the first word.
+    __device__ __forceinline__ void step2(const WorldView& W)
+    {
+        (void)W;
+#ifdef VXRT_HOST_CHECK
+        for (int p = 0; p < 2; ++p) {
+            if (st != ST_WALK)
+                return;
+            const uint32_t i1 = idx;
+#ifdef VXRT_HOST_DEBUG
+            if (i1 > (1u << 26)) { fprintf(stderr, "wild idx %u rem %x rp %x rpp %x fix %u di %d %d %d fine %d tl %g thi %g\n", i1, rem, rp, rpp, fix, (int)di_x, (int)di_y, (int)di_z, (int)lane_fine(), tl, t_hi); abort(); }
+#endif
+            const uint32_t word = bits[i1 >> 5];
+            const bool a0 = tn_x < tn_y && tn_x < tn_z;
+            const bool a1 = !(tn_x < tn_y) && tn_y < tn_z;
+            tp = tl;
+            rpp = rp;
+            rp = rem;
+            tl = lo(lo(tn_x, tn_y), tn_z);
+            if (a0) {
+                tn_x += fabsf(ivx);
+                idx += di_x;
+                rem -= kRemDecX;
+            } else if (a1) {
+                tn_y += fabsf(ivy);
+                idx += di_y;
+                rem -= kRemDecY;
+            } else {
+                tn_z += fabsf(ivz);
+                idx += di_z;
+                rem -= kRemDecZ;
+            }
+            if (p == 0) {
+                idx -= fix;
+                fix = 0u;
+            }
+            const bool sus = tl > t_hi, gd = (rem & kRemGuards) != 0u;
+            const bool solid = ((word >> (i1 & 31u)) & 1u) != 0u;
+            if (solid)
+                st = lane_fine() ? (uint32_t)ST_ENDHIT : (uint32_t)ST_BOX;
+            else if (sus || gd)
+                st = ST_END;
+        }
+#else
+        const lanemask_t w1 = lane_mask(st == ST_WALK);
+        lanemask_t sus1, gd1, sus2, gd2;
+        // ---- probe 1
+        const uint32_t i1 = idx;
+        const uint32_t word1 = bits[i1 >> 5];
+        advance(w1, sus1, gd1);
+        idx -= fix;
+        fix = 0u;
+        // ---- probe 2's load
+        const uint32_t i2 = idx;
+        const uint32_t word2 = bits[i2 >> 5];
+        // ---- probe 1: who stood on an occupied cell
+        const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w1;
+        const lanemask_t stop1 = h1 | sus1 | gd1;
+        const lanemask_t w2 = w1 & ~stop1;
+        advance(w2, sus2, gd2);
+        const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
+        const lanemask_t h = h1 | h2;
+        const lanemask_t other = ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
+        const lanemask_t park = h & ~fine_m, lhit = h & fine_m;
+        unsigned long long save;
+        asm volatile("s_mov_b64 %[save], exec\n\t"
+                     "s_mov_b64 exec, %[park]\n\t"
+                     "v_mov_b32 %[st], 1\n\t"
+                     "s_mov_b64 exec, %[lhit]\n\t"
+                     "v_mov_b32 %[st], 5\n\t"
+                     "s_mov_b64 exec, %[other]\n\t"
+                     "v_mov_b32 %[st], 2\n\t"
+                     "s_mov_b64 exec, %[save]"
+                     : [st] "+v"(st), [save] "=&s"(save)
+                     : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
+#endif
+    }
+
+#ifndef VXRT_HOST_CHECK
+    // One speculative DDA advance (:293-322) of the lanes in `w`, in place.  Outputs (limited to w): sus = lanes whose t
+    // is beyond t_hi, gd = lanes with a guard bit in rem (the advance left the grid).
+    __device__ __forceinline__ void advance(const lanemask_t w, lanemask_t& sus, lanemask_t& gd)
+    {
+        unsigned long long save;
+        uint32_t tmp;
+        asm volatile(
+            "s_mov_b64 %[save], exec\n\t"
+            "s_mov_b64 exec, %[w]\n\t"
+            // compares of the three tMax under w: their masks are limited to w
+            "v_cmp_lt_f32 s[84:85], %[tx], %[ty]\n\t"
+            "v_cmp_lt_f32 s[86:87], %[tx], %[tz]\n\t"
+            "v_cmp_lt_f32 s[88:89], %[ty], %[tz]\n\t"
+            // history, then t of this advance
+            "v_mov_b32 %[tp], %[tl]\n\t"
+            "v_mov_b32 %[rpp], %[rp]\n\t"
+            "v_mov_b32 %[rp], %[rem]\n\t"
+            "v_min3_f32 %[tl], %[tx], %[ty], %[tz]\n\t"
+            // x: tx < ty && tx < tz; y: !(tx < ty) && ty < tz; z: the rest of w
+            "s_and_b64 s[86:87], s[84:85], s[86:87]\n\t"
+            "s_andn2_b64 s[88:89], s[88:89], s[84:85]\n\t"
+            "s_or_b64 s[84:85], s[86:87], s[88:89]\n\t"
+            "s_andn2_b64 s[84:85], %[w], s[84:85]\n\t"
+            "s_mov_b64 exec, s[86:87]\n\t"
+            "v_add_f32 %[tx], %[tx], |%[ivx]|\n\t"
+            "v_add_u32 %[idx], %[idx], %[dix]\n\t"
+            "v_add_u32 %[rem], -1, %[rem]\n\t"
+            "s_mov_b64 exec, s[88:89]\n\t"
+            "v_add_f32 %[ty], %[ty], |%[ivy]|\n\t"
+            "v_add_u32 %[idx], %[idx], %[diy]\n\t"
+            "v_add_u32 %[rem], 0xfffff800, %[rem]\n\t"
+            "s_mov_b64 exec, s[84:85]\n\t"
+            "v_add_f32 %[tz], %[tz], |%[ivz]|\n\t"
+            "v_add_u32 %[idx], %[idx], %[diz]\n\t"
+            "v_add_u32 %[rem], 0xffe00000, %[rem]\n\t"
+            "s_mov_b64 exec, %[w]\n\t"
+            "v_cmp_gt_f32 %[sus], %[tl], %[thi]\n\t"
+            "v_and_b32 %[tmp], 0x80100400, %[rem]\n\t"
+            "v_cmp_ne_u32 %[gd], 0, %[tmp]\n\t"
+            "s_mov_b64 exec, %[save]"
+            : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
+              [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [gd] "=&s"(gd), [save] "=&s"(save), [tmp] "=&v"(tmp)
+            : [w] "s"(w), [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [dix] "v"(di_x), [diy] "v"(di_y), [diz] "v"(di_z),
+              [thi] "v"(t_hi)
+            : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
+    }
+#endif
+
+    __device__ __forceinline__ void probe_group(const WorldView& W) { step2(W); }
+
+    // Raytrace's epilogue (:514-523); the ray has ended (st == ST_DONE)
+    __device__ __forceinline__ void result(const WorldView& W, TraceResult& out) const
+    {
+        const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
+        const bool hit = (ray_codes & 0x40u) != 0u;
+        const int total_ = (int)cold[CF_TOTAL * 64];
+        const int hx = (int)cold[CF_CHX * 64], hy = (int)cold[CF_CHY * 64], hz = (int)cold[CF_CHZ * 64];
+        out.hit = hit;
+        out.steps = total_;
+        // hitPosition of the walk that ended the ray, as phase_end computed it (the same operands, the same operations)
+        const bool is_fine = lane_fine();
+        const float ox = (float)hx * W.ff, oy = (float)hy * W.ff, oz = (float)hz * W.ff;
+        out.pos = mk3(is_fine ? point.x + ox : point.x * W.ff, is_fine ? point.y + oy : point.y * W.ff,
+                      is_fine ? point.z + oz : point.z * W.ff);
+        // brick HitCell = the clamped cell that was probed last (rp: the walk does not advance past a hit)
+        int x, y, z;
+        cells_of(W, true, rp, x, y, z);
+        out.vx = hx * W.f + min(x, W.f - 1);
+        out.vy = hy * W.f + min(y, W.f - 1);
+        out.vz = hz * W.f + min(z, W.f - 1);
+        const bool at_entry = hit && total_ == 0;
+        out.ncode = at_entry ? (ray_codes & 7u) : ((ray_codes >> 3) & 7u);
+        out.normal = normal_decode(out.ncode);
+        if (at_entry)
+            out.pos = mk3(__uint_as_float(cold[CF_START_X * 64]) * W.ff, __uint_as_float(cold[CF_START_Y * 64]) * W.ff,
+                          __uint_as_float(cold[CF_START_Z * 64]) * W.ff);
+    }
+};
+
+// one ray per lane, entered by the whole wave at a converged point (host check and the batch test kernel)
+__device__ inline void trace_wave2(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
+                                   TraceResult& out, uint32_t* cold_column)
+{
+    WaveTracer2 T;
+    T.init(W, cold_column);
+    if (active)
+        T.begin_ray(W, origin, ray, max_steps);
+    T.after_begin_ray(active);
+    for (;;) {
+        const unsigned long long m_walk = __ballot(T.st == ST_WALK);
+        const unsigned long long m_box = __ballot(T.st == ST_BOX);
+        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        if ((m_walk | m_box | m_end) == 0ull)
+            break;
+        const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
+        if (vote_run(n_end, n_walk + n_box, VXRT_VOTE_END))
+            T.phase_end(W);
+        if (vote_run(n_box, n_walk, VXRT_VOTE_BOX))
+            T.phase_box(W);
+        T.probe_group(W);
+    }
+    if (active)
+        T.result(W, out);
+}
+
+}  // namespace vxrt

@@ -311,7 +311,7 @@ class Context:
         return bool(self._L.vxrt_has_experiments())
 
     KERNEL_NAMES = {0: "k_render_wave", 1: "k_render", 2: "k_render_persist", 3: "k_render_pool", 5: "k_render_persist_lds",
-                    6: "k_ts_trace"}
+                    6: "k_ts_trace", 7: "k_render_persist2"}
 
     def kernel_for_launch(self, width: int, height: int, opts: "RenderOptions | None" = None, nviews: int = 0) -> int:
         """The kernel (0, 1, 2, 3 or 5) a RenderScreen (nviews = 0) or RenderViews launch of this shape runs under the
