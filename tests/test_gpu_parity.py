@@ -146,8 +146,9 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
 @pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
 def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
     """Variants: 1 straightforward per-lane loops, 2 persistent waves with a pixel queue, 5 the same with its cold state
-    in LDS, 6 the traversal / shading pipeline over ray queues.  All give the oracle's bits, in every render mode.
-    (Batch traces: 1 straightforward, anything else the wave-level tracer.)"""
+    in LDS, 6 the traversal / shading pipeline over ray queues, 7 = 5 on the tracer of vxrt_wave2.hpp (speculative
+    exec-masked advance, packed step counters; the default for large launches).  All give the oracle's bits, in every
+    render mode.  (Batch traces: 1 straightforward, 7 the second tracer one ray per lane, anything else the first.)"""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
@@ -637,20 +638,22 @@ def test_kernel_for_launch_reports_the_policy(eng, vxo):
     try:
         ctx.set_kernel_variant(4)
         shaded = vx.RenderOptions(shadow=True, bounce_samples=1)
-        assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 5       # several views
-        assert ctx.kernel_for_launch(1920, 1080, shaded) == 5                   # 6.2 M rays
+        # (7 = the persistent kernel on the tracer of vxrt_wave2.hpp; worlds whose coarse grid does not fit its packed step
+        # counters -- more than 1022 x 510 x 1022 cells -- get 5, the same kernel on the round-2 tracer)
+        assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 7       # several views
+        assert ctx.kernel_for_launch(1920, 1080, shaded) == 7                   # 6.2 M rays
         assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions()) == 2       # 2.1 M rays, primary only
-        assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions()) == 5       # 8.3 M rays
+        assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions()) == 7       # 8.3 M rays
         assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions(shadow=True, checkerboard=True)) == 2  # half the rows
         assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions(shadow=True, strip_rows=16, strip_count=8, strip_index=3,
                                                                   compact=True)) == 2   # a 1/8 shard of a 4K frame
-        for v in (1, 2, 5, 6):
+        for v in (1, 2, 5, 6, 7):
             ctx.set_kernel_variant(v)
             assert ctx.kernel_for_launch(640, 480, shaded) == v
         # the wavefront pipeline keeps one queue per ray generation: beyond 64 generations the fused kernel runs
         ctx.set_kernel_variant(6)
         assert ctx.kernel_for_launch(640, 480, vx.RenderOptions(shadow=True, bounce_samples=100)) == 5
-        assert ctx.KERNEL_NAMES[5] == "k_render_persist_lds" and ctx.KERNEL_NAMES[6] == "k_ts_trace"
+        assert ctx.KERNEL_NAMES[5] == "k_render_persist_lds" and ctx.KERNEL_NAMES[6] == "k_ts_trace" and ctx.KERNEL_NAMES[7] == "k_render_persist2"
         # variants 0 and 3 are A/B kernels of the experiments build (libvxrt_exp.so): the product library refuses them
         for v in (0, 3):
             if ctx.has_experiments():

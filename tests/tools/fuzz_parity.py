@@ -56,7 +56,7 @@ while time.time() < t_end:
             fail("batch variant %d" % variant, seed, "positions differ")
         if not np.array_equal(g["normal"], cpu["normal"]):
             fail("batch variant %d" % variant, seed, "normals differ")
-    rays_checked += 2 * n
+    rays_checked += 3 * n
     # one random frame configuration, all three render kernels
     W, H = int(rng.integers(40, 400)), int(rng.integers(30, 260))
     cam = str(rng.choice(["A", "B", "C", "D"]))
@@ -101,7 +101,7 @@ while time.time() < t_end:
             fail("multi-view launch, view %d" % j, seed, "cam %s %dx%d %r" % (cam, W, H, kw))
     ctx.set_kernel_variant(4)
     ctx.frame_stats()
-    frames_checked += (6 if ctx.has_experiments() else 4) + 3
+    frames_checked += (7 if ctx.has_experiments() else 5) + 3
     rounds += 1
     if rounds % 10 == 0:
         print("round %d (seed %d): %d rays, %d frames checked, all equal" % (rounds, seed, rays_checked, frames_checked), flush=True)

@@ -379,6 +379,8 @@ int vxrt_kernel_for_launch(const vxrt_ctx* c, uint32_t width, uint32_t height, c
         return -1;
     vxrt::RenderArgs A;
     memset(&A, 0, sizeof(A));
+    if (c->has_world)
+        A.W = c->view;  // (variant 7 depends on the resident world's dimensions: vxrt_wave2.hpp, tracer2_fits)
     A.width = width;
     A.shadow = fl->shadow ? 1 : 0;
     A.bounce_samples = fl->bounce_samples;

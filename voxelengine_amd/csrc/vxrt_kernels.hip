@@ -689,7 +689,7 @@ int resolve_render_variant(const RenderArgs& A, int variant)
     if (variant == 4) {
         const unsigned long long rays = (unsigned long long)A.width * A.launch_rows *
                                         (1ull + (A.shadow ? 1ull : 0ull) + (A.bounce_samples > 0 ? 1ull : 0ull));
-        variant = (A.nviews >= 2 || rays >= 4000000ull) ? 5 : 2;
+        variant = (A.nviews >= 2 || rays >= 4000000ull) ? 7 : 2;  // (7 falls back to 5 below if the world does not fit it)
     }
 #ifdef VXRT_EXPERIMENTS
     if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))

@@ -17,6 +17,19 @@ namespace vxrt {
 #ifndef VXRT_PERSIST2_OCC
 #define VXRT_PERSIST2_OCC 5
 #endif
+// Vote thresholds of this kernel (vote_run: a parked phase runs when parked * N >= the other live lanes).  The probes
+// of this tracer cost less than half of WaveTracer's while the phases cost about the same, so waiting for more lanes pays:
+// end-of-walk and ray-finished wait until their lanes are as many as the others (N = 1), the tight-box phase (which now
+// also enters the brick) until they are half as many.  Sweep in profiles/r03_variant7.md.
+#ifndef VXRT_VOTE2_NEXT
+#define VXRT_VOTE2_NEXT 1
+#endif
+#ifndef VXRT_VOTE2_END
+#define VXRT_VOTE2_END 1
+#endif
+#ifndef VXRT_VOTE2_BOX
+#define VXRT_VOTE2_BOX 2
+#endif
 #define PX_LD_U(f, v) do { if (LDS) v = PX[(f) * 64]; } while (0)
 #define PX_ST_U(f, v) do { if (LDS) PX[(f) * 64] = (uint32_t)(v); } while (0)
 #define PX_LD_I(f, v) do { if (LDS) v = (int)PX[(f) * 64]; } while (0)
@@ -126,7 +139,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // hits can enter its brick, and a lane whose ray ends can start its next ray, in the same round instead of
         // waiting for the next round's vote (+4 % with several probes per round; with one probe per round it was +-0)
         int c_walk = n_walk, c_box = n_box, c_end = n_end, c_next = n_next;
-        if (vote_run(c_box, c_walk, VXRT_VOTE_BOX)) {
+        if (vote_run(c_box, c_walk, VXRT_VOTE2_BOX)) {
             if (STATS) {
                 dg_runs[2] += 1u;
                 dg_lanes[2] += (unsigned)c_box;
@@ -139,7 +152,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             c_walk = __popcll(__ballot(T.st == ST_WALK));
             c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
         }
-        if (vote_run(c_end, c_walk + c_box, VXRT_VOTE_END)) {
+        if (vote_run(c_end, c_walk + c_box, VXRT_VOTE2_END)) {
             if (STATS) {
                 dg_runs[1] += 1u;
                 dg_lanes[1] += (unsigned)c_end;
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
         // launch; one begin_ray at the end of the phase serves them all (its 7 divisions + square root are the
         // expensive part of this phase).
-        if (vote_run(c_next, c_walk + c_box + c_end, VXRT_VOTE_NEXT)) {
+        if (vote_run(c_next, c_walk + c_box + c_end, VXRT_VOTE2_NEXT)) {
             if (STATS) {
                 dg_runs[0] += 1u;
                 dg_lanes[0] += (unsigned)c_next;
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             if (g > 0) {
                 int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
                     m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
-                if (vote_run(m_b, m_w, VXRT_VOTE_BOX)) {
+                if (vote_run(m_b, m_w, VXRT_VOTE2_BOX)) {
                     if (STATS) {
                         dg_runs[2] += 1u;
                         dg_lanes[2] += (unsigned)m_b;
@@ -409,7 +422,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                     m_w = __popcll(__ballot(T.st == ST_WALK));
                     m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
                 }
-                if (vote_run(m_e, m_w + m_b, VXRT_VOTE_END)) {
+                if (vote_run(m_e, m_w + m_b, VXRT_VOTE2_END)) {
                     if (STATS) {
                         dg_runs[1] += 1u;
                         dg_lanes[1] += (unsigned)m_e;
