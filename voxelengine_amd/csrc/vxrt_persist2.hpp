@@ -19,10 +19,10 @@ namespace vxrt {
 #endif
 // Vote thresholds of this kernel (vote_run: a parked phase runs when parked * N >= the other live lanes).  The probes
 // of this tracer cost less than half of WaveTracer's while the phases cost about the same, so waiting for more lanes pays:
-// end-of-walk and ray-finished wait until their lanes are as many as the others (N = 1), the tight-box phase (which now
+// end-of-walk waits until its lanes are as many as the others (N = 1), ray-finished and the tight-box phase (which now
 // also enters the brick) until they are half as many.  Sweep in profiles/r03_variant7.md.
 #ifndef VXRT_VOTE2_NEXT
-#define VXRT_VOTE2_NEXT 1
+#define VXRT_VOTE2_NEXT 2
 #endif
 #ifndef VXRT_VOTE2_END
 #define VXRT_VOTE2_END 1

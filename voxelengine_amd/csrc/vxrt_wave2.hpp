@@ -54,6 +54,20 @@ __host__ __device__ inline bool tracer2_fits(const WorldView& W)
     return W.cx <= 1022 && W.cz <= 1022 && W.cy <= 510 && W.f <= 32 && W.cx + W.cy + W.cz + 4 < kMaxSteps;
 }
 
+// The machine's min / max as single instructions (fminf / fmaxf compile to the instruction plus one canonicalising
+// v_max_f32 per operand under IEEE rules).  Callers guarantee ordinary operands (no NaN; see slab_fast).
+#ifndef VXRT_HOST_CHECK
+__device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+#else
+__device__ __forceinline__ float vmin(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float vmax(float a, float b) { return a > b ? a : b; }
+__device__ __forceinline__ float vmin3(float a, float b, float c) { return vmin(vmin(a, b), c); }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
+#endif
+
 __device__ __forceinline__ uint32_t rem_fx(uint32_t r) { return r & 0x7FFu; }
 __device__ __forceinline__ uint32_t rem_fy(uint32_t r) { return (r >> 11) & 0x3FFu; }
 __device__ __forceinline__ uint32_t rem_fz(uint32_t r) { return r >> 21; }
@@ -77,7 +91,7 @@ struct WaveTracer2 {
     f3 ws;
     uint32_t rem0;            // sum of rem's fields at the start of the walk
     float t_hi_real;
-    bool special;             // per ray: a direction component is zero or below 2^-40
+    bool special;             // per ray: a direction component is zero or below 2^-40, or a start component is -0.0
     uint32_t dn;              // per ray: bit k set where the ray does not move up axis k (d_k <= 0)
     f3 point;                 // HitIntersectedPoint of the walk that ended (tight-box phase / end-of-walk phase)
     lanemask_t fine_m;        // wave mask: lanes walking inside a brick
@@ -128,6 +142,26 @@ struct WaveTracer2 {
         code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
                             : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
         return !(t_out < hi(t_in, 0.0f));
+    }
+
+    // The same test with the machine's min / max (v_min_f32, v_max3_f32 ...: 8 instructions instead of 16 compare + select
+    // pairs).  They differ from lo() / hi() only when an operand is a NaN (0 * inf: a direction component so small that
+    // its reciprocal overflows) or when a zero of the other sign wins (visible only in the sign of a zero of p, and only
+    // if a start component is -0.0): both are `special` rays (begin_ray), which keep slab().
+    __device__ __forceinline__ bool slab_fast(f3 s, f3 bmin, f3 bmax, f3& p, uint32_t& code) const
+    {
+        float ax = (bmin.x - s.x) * ivx, bx = (bmax.x - s.x) * ivx;
+        float ay = (bmin.y - s.y) * ivy, by = (bmax.y - s.y) * ivy;
+        float az = (bmin.z - s.z) * ivz, bz = (bmax.z - s.z) * ivz;
+        float nx = vmin(ax, bx), fx = vmax(ax, bx);
+        float ny = vmin(ay, by), fy = vmax(ay, by);
+        float nz = vmin(az, bz), fz = vmax(az, bz);
+        float t_in = vmax3(nx, ny, nz);
+        float t_out = vmin3(fx, fy, fz);
+        p = mk3(s.x + t_in * d.x, s.y + t_in * d.y, s.z + t_in * d.z);
+        code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
+                            : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
+        return !(t_out < vmax(t_in, 0.0f));
     }
 
     // cell coordinates (unclamped) of a rem word of the current walk
@@ -221,7 +255,7 @@ struct WaveTracer2 {
             const uint32_t Fb = __float_as_uint(W.ff);
             const float hx = (__uint_as_float(Fb & mx) - s.x) * ivx, hy = (__uint_as_float(Fb & my) - s.y) * ivy,
                         hz = (__uint_as_float(Fb & mz) - s.z) * ivz;
-            hi_t = fminf(fminf(hx, hy), hz);
+            hi_t = vmin3(hx, hy, hz);
             hi_t = hi_t - fabsf(hi_t) * kThrEps;
             hi_t = special ? -kInf : hi_t;
             // entry side: a start outside [0, f] on some axis (sign bit of s_k or of f - s_k)
@@ -261,7 +295,8 @@ struct WaveTracer2 {
         cold[CF_START_Z * 64] = __float_as_uint(s0.z);
         cold[CF_LAST_CI * 64] = 0xFFFFFFFFu;  // previous_cell as its cell index (unique per cell); none yet
         cold[CF_TOTAL * 64] = 0u;
-        special = !(fabsf(d.x) >= kMinFastDir && fabsf(d.y) >= kMinFastDir && fabsf(d.z) >= kMinFastDir);
+        special = !(fabsf(d.x) >= kMinFastDir && fabsf(d.y) >= kMinFastDir && fabsf(d.z) >= kMinFastDir) ||
+                  __float_as_uint(s0.x) == 0x80000000u || __float_as_uint(s0.y) == 0x80000000u || __float_as_uint(s0.z) == 0x80000000u;
         dn = (d.x > 0 ? 0u : 1u) | (d.y > 0 ? 0u : 2u) | (d.z > 0 ? 0u : 4u);
         start_walk<false>(W, s0);
     }
@@ -419,7 +454,11 @@ struct WaveTracer2 {
                           ((float)((e >> 25) & 31u) + 1) * W.inv_f + fqz);
             f3 bp;
             uint32_t bc;
-            const bool box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
+            bool box_hit = slab_fast(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
+            if (__ballot(special) != 0ull) {
+                if (special)
+                    box_hit = slab(ws, bmin, bmax, bp, bc) && bmin.x <= bmax.x;
+            }
             if (box_hit) {
                 // the coarse walk ends here (:395-407): its steps, its HitIntersectedPoint (`step != 0`, :266)
                 const uint32_t steps = rem0 - rem_sum(rp);
