@@ -46,9 +46,9 @@ int vxrt_destroy(vxrt_ctx *ctx);
 const char *vxrt_last_error(void);
 int vxrt_synchronize(vxrt_ctx *ctx);
 /* kernel implementation used by vxrt_render / vxrt_render_views (and vxrt_trace_batch).  All give identical results.
- *   4 (default) = persistent waves, the kernel picked per launch from measurements: 5 for a launch over several views
- *       and for a large single-view launch (at least 4 M rays, counting one shadow and one bounce ray per pixel where
- *       enabled), 2 for a small one;
+ *   4 (default) = persistent waves, the kernel picked per launch from measurements: 7 (5 for a world 7 does not fit)
+ *       for a launch over several views and for a large single-view launch (at least 4 M rays, counting one shadow and
+ *       one bounce ray per pixel where enabled), 2 for a small one;
  *   2 = persistent waves, one pixel chain per lane, pixels from a tile queue;
  *   5 = 2 with the state only the parked phases touch in LDS: 96 VGPRs, 5 waves per SIMD;
  *   6 = wavefront pipeline: a traversal kernel and a shading kernel that hand each other prepared ray records through HBM,
@@ -56,10 +56,15 @@ int vxrt_synchronize(vxrt_ctx *ctx);
  *       view.  Its queues live in a workspace of 178 bytes per pixel of the launch (186 with a hit-index
  *       AOV), taken from a ring of three per context: a fourth variant-6 launch in flight waits for the oldest; the first
  *       launch of a shape allocates, so it cannot happen inside a stream capture;
+ *   7 = 5 on the tracer of csrc/vxrt_wave2.hpp (round 3): the DDA advance speculative and exec-masked, the cell as a bit
+ *       index + three packed step counters, the region check by a threshold in the probe and exactly at the end of a
+ *       walk, brick entry inside the tight-box phase.  What 4 picks for multi-view and large launches; needs a coarse grid
+ *       of at most 1022 x 510 x 1022 cells whose dimensions sum to less than 2044 (else the launch runs 5);
  *   1 = straightforward per-lane loops (the on-device cross-check).
  * Variants 0 (wave-level state machine, one lane per pixel) and 3 (pixel chains pooled in LDS) are A/B kernels of the
  * experiments build (libvxrt_exp.so) and are refused by the product library.  (Batch traces: 1 = straightforward,
- * 0 = the wave-level tracer, anything else = the wave-level tracer behind a persistent ray queue.) */
+ * 0 = the wave-level tracer, 7 = the tracer of vxrt_wave2.hpp one ray per lane, anything else = the wave-level tracer behind a
+ * persistent ray queue.) */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 /* 1 when the library was built with -DVXRT_EXPERIMENTS (variants 0 and 3, development knobs read from the environment) */
 int vxrt_has_experiments(void);

@@ -630,10 +630,28 @@ def test_errors_are_reported_not_swallowed(eng, vxo):
     c2.close()
 
 
+def test_world_too_wide_for_the_second_tracer_runs_the_first(eng, vxo):
+    """Variant 7 packs the steps left to the coarse grid's faces into 11 + 10 + 11 bits: a coarse grid of 1024 cells along x
+    does not fit, the policy (and a forced 7) falls back to 5, and the frame is the oracle's all the same."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 8192, 64, 64, 8)
+    _upload(ctx, w)
+    default = ctx.kernel_variant
+    try:
+        shaded = vx.RenderOptions(shadow=True, bounce_samples=1)
+        for v in (4, 7):
+            ctx.set_kernel_variant(v)
+            assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 5
+            _assert_frame_equal(*_render_both(eng, vxo, w, 160, 96, "A", frame_number=3, shadow=1, bounce_samples=1))
+    finally:
+        ctx.set_kernel_variant(default)
+
+
 def test_kernel_for_launch_reports_the_policy(eng, vxo):
     """vxrt_kernel_for_launch: what the default (variant 4) resolves to per launch shape, and that a forced variant is
     reported as itself."""
     vx, ctx, torch = eng
+    _upload(ctx, vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32))  # (a world variant 7 fits: 8 x 8 x 8 bricks)
     default = ctx.kernel_variant
     try:
         ctx.set_kernel_variant(4)

@@ -47,9 +47,10 @@ ent = {
         "wave_time_issuing": round(vals["SQ_ACTIVE_INST_ANY"] / vals["SQ_WAVE_CYCLES"], 3),
         "wave_time_waiting_to_issue": round(vals["SQ_WAIT_INST_ANY"] / vals["SQ_WAVE_CYCLES"], 3),
         "wave_time_waiting_for_memory": round(vals["SQ_WAIT_ANY"] / vals["SQ_WAVE_CYCLES"], 3),
-        "note": "instructions / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 cycles; the kernel's own mask-logic instruction style reaches "
-                "1.7-2.1 cycles per instruction per SIMD in the pinned-stream microbenchmark (profiles/r02b_issue_rate_ubench.txt, "
-                "mask_logic at 4-5 waves per SIMD)",
+        "note": "instructions / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 cycles.  A SIMD retires a wave64 vector instruction in ~2.3 "
+                "cycles (fast class) or ~4.15 (slow class), beside one scalar instruction per ~4.15 (profiles/r03_instr_cost.md); "
+                "cycles_per_valu_per_simd near the kernel's mean instruction price (tools/isa_cost.py: ~3.7) means the vector pipe "
+                "is busy",
     },
 }
 tj = os.path.join(ROOT, "profiles", "traffic.json")

@@ -30,6 +30,23 @@ namespace vxrt {
 #ifndef VXRT_VOTE2_BOX
 #define VXRT_VOTE2_BOX 2
 #endif
+// A/B knob: absolute thresholds instead (a phase runs when at least K lanes wait for it, or nobody else is left)
+#ifdef VXRT_VOTE2_ABS_BOX
+__device__ __forceinline__ bool vote2(int parked, int others, int num, int k)
+{
+    (void)num;
+    return parked >= k || (parked > 0 && others == 0);
+}
+#else
+#define VXRT_VOTE2_ABS_BOX 0
+#define VXRT_VOTE2_ABS_END 0
+#define VXRT_VOTE2_ABS_NEXT 0
+__device__ __forceinline__ bool vote2(int parked, int others, int num, int k)
+{
+    (void)k;
+    return vote_run(parked, others, num);
+}
+#endif
 #define PX_LD_U(f, v) do { if (LDS) v = PX[(f) * 64]; } while (0)
 #define PX_ST_U(f, v) do { if (LDS) PX[(f) * 64] = (uint32_t)(v); } while (0)
 #define PX_LD_I(f, v) do { if (LDS) v = (int)PX[(f) * 64]; } while (0)
@@ -139,7 +156,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // hits can enter its brick, and a lane whose ray ends can start its next ray, in the same round instead of
         // waiting for the next round's vote (+4 % with several probes per round; with one probe per round it was +-0)
         int c_walk = n_walk, c_box = n_box, c_end = n_end, c_next = n_next;
-        if (vote_run(c_box, c_walk, VXRT_VOTE2_BOX)) {
+        if (vote2(c_box, c_walk, VXRT_VOTE2_BOX, VXRT_VOTE2_ABS_BOX)) {
             if (STATS) {
                 dg_runs[2] += 1u;
                 dg_lanes[2] += (unsigned)c_box;
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             c_walk = __popcll(__ballot(T.st == ST_WALK));
             c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
         }
-        if (vote_run(c_end, c_walk + c_box, VXRT_VOTE2_END)) {
+        if (vote2(c_end, c_walk + c_box, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
             if (STATS) {
                 dg_runs[1] += 1u;
                 dg_lanes[1] += (unsigned)c_end;
@@ -169,7 +186,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
         // launch; one begin_ray at the end of the phase serves them all (its 7 divisions + square root are the
         // expensive part of this phase).
-        if (vote_run(c_next, c_walk + c_box + c_end, VXRT_VOTE2_NEXT)) {
+        if (vote2(c_next, c_walk + c_box + c_end, VXRT_VOTE2_NEXT, VXRT_VOTE2_ABS_NEXT)) {
             if (STATS) {
                 dg_runs[0] += 1u;
                 dg_lanes[0] += (unsigned)c_next;
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             if (g > 0) {
                 int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
                     m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
-                if (vote_run(m_b, m_w, VXRT_VOTE2_BOX)) {
+                if (vote2(m_b, m_w, VXRT_VOTE2_BOX, VXRT_VOTE2_ABS_BOX)) {
                     if (STATS) {
                         dg_runs[2] += 1u;
                         dg_lanes[2] += (unsigned)m_b;
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                     m_w = __popcll(__ballot(T.st == ST_WALK));
                     m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
                 }
-                if (vote_run(m_e, m_w + m_b, VXRT_VOTE2_END)) {
+                if (vote2(m_e, m_w + m_b, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
                     if (STATS) {
                         dg_runs[1] += 1u;
                         dg_lanes[1] += (unsigned)m_e;
