@@ -375,14 +375,15 @@ def run(args):
                          "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1),
                          # what the fraction above is and is not: the contract's yardstick is ALGORITHMIC bytes on the
                          # reference's data layout; the bytes that really cross the HBM interface (PMC, profiles/) are a
-                         # fraction of them, and the kernel's physical limiter is the vector ALU pipe
+                         # fraction of them, and the kernel's physical limiter is instruction issue (vector ALU pipe ~93 % busy)
                          "convention": "achieved = algorithmic bytes (SURVEY.md 8d: 28 B per coarse probe, 24 B per brick entry, "
                                        "4 B per brick probe, 4 B per pixel) / launch time; not measured HBM traffic",
                          "traffic_frac": None if traffic is None else round(traffic / avg_kernel_s / 1e9 / HBM_PEAK_GBS, 5),
-                         "physical_bound": "vector ALU pipe (divergent traversal): a SIMD retires a wave64 vector instruction in "
-                                           "~2.3 cycles (add/mul/logic/shift on vector or constant operands) or ~4.15 (compares, "
-                                           "selects, min/max, conversions, three-operand forms, scalar operands); priced that way the "
-                                           "pipe is ~95 % busy (profiles/r03_instr_cost.md)",
+                         "physical_bound": "instruction issue (divergent traversal): a SIMD retires a wave64 vector instruction in ~2.3 "
+                                           "cycles (add/mul/logic/shift on vector or constant operands) or ~4.15 (compares, selects, "
+                                           "min/max, conversions, three-operand forms, scalar operands); priced that way the vector ALU "
+                                           "pipe is ~93 % busy, and the launch runs at ~2.4 cycles per issued instruction per SIMD, "
+                                           "vector or scalar (profiles/r03_instr_cost.md, profiles/r03_variant7.md)",
                          "issue_utilisation": issue, "stale_profile": stale_profile},
         }
         if rehearse or args.force_gather:  # the gathered frames of the last step must equal single-GPU, single-view renders of the same frames
