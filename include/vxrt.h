@@ -63,8 +63,9 @@ int vxrt_synchronize(vxrt_ctx *ctx);
  *   1 = straightforward per-lane loops (the on-device cross-check).
  * Variants 0 (wave-level state machine, one lane per pixel) and 3 (pixel chains pooled in LDS) are A/B kernels of the
  * experiments build (libvxrt_exp.so) and are refused by the product library.  (Batch traces: 1 = straightforward,
- * 0 = the wave-level tracer, 7 = the tracer of vxrt_wave2.hpp one ray per lane, anything else = the wave-level tracer behind a
- * persistent ray queue.) */
+ * 0 = the wave-level tracer, 7 = the tracer of vxrt_wave2.hpp one ray per lane; anything else: the wave-level tracer behind a
+ * persistent ray queue for batches of at least 8 rays per lane of the persistent grid, and below that one ray per lane -- on the
+ * tracer of vxrt_wave2.hpp (4, 5, 6; worlds it fits, no statistics requested) or on the first tracer (2).) */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
 /* 1 when the library was built with -DVXRT_EXPERIMENTS (variants 0 and 3, development knobs read from the environment) */
 int vxrt_has_experiments(void);

@@ -23,7 +23,7 @@ def run(ctx, o, d, label, reps=20):
     steps = torch.empty(n, dtype=torch.int32, device="cuda")
     hit = torch.empty(n, dtype=torch.uint8, device="cuda")
     vox = torch.empty(n, dtype=torch.int64, device="cuda")
-    for variant in (2, 1):
+    for variant in (2, 7, 1):
         ctx.set_kernel_variant(variant)
         for _ in range(3):
             ctx.trace_batch_device(do, dd, n, pos, nrm, steps, hit, vox)

@@ -809,12 +809,17 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
     // default: persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the
     // persistent grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
-    if (variant == 7 && !stats && !B.dbg_trace && tracer2_fits(B.W)) {
+    const bool persistent = variant >= 2 && variant != 7 && B.ticket && !B.dbg_trace && B.persistent_waves &&
+                            B.n >= 8ull * 64ull * B.persistent_waves;  // (render variants 2..6 are all 'persistent' for a batch)
+    // One ray per lane on the tracer of vxrt_wave2.hpp: variant 7 always (so that tests reach that tracer with batches of any
+    // size), and what every persistent variant but 2 takes for batches too small for the queue -- BASELINE configs[0]'s
+    // million-ray fan: 17.7 Grays/s against 14.0 for k_trace_batch_wave and 16.6 for the straightforward loops
+    // (tools/batch_probe.py).  Variant 2 keeps the first tracer (tests and randomised parity run both).
+    if ((variant == 7 || (variant >= 3 && !persistent)) && !stats && !B.dbg_trace && tracer2_fits(B.W)) {
         hipLaunchKernelGGL(k_trace_batch_wave2, grid, block, 0, stream, B);
         return hipSuccess;
     }
-    if (variant >= 2 && B.ticket && !B.dbg_trace  // (render variants 3..5 are all 'persistent' for a batch)
-         && B.persistent_waves && B.n >= 8ull * 64ull * B.persistent_waves) {
+    if (persistent) {
         const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
         if (e != hipSuccess)
             return e;
