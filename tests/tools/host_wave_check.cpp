@@ -86,7 +86,11 @@ int main(int argc, char** argv)
         if (tracer2_fits(W)) {
             TraceResult t4{};
             trace_wave2(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column);
-            bool s4 = t4.hit == t.hit && t4.steps == t.steps;
+            // ... and with three probe pairs between two rounds of votes, as k_render_persist2 runs it
+            TraceResult t5{};
+            trace_wave2<3>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column);
+            bool s4 = t4.hit == t.hit && t4.steps == t.steps && t5.hit == t.hit && t5.steps == t.steps;
+            if (t.hit) s4 = s4 && memcmp(&t5.pos, &t.pos, 12) == 0 && memcmp(&t5.normal, &t.normal, 12) == 0 && t5.vx == t.vx && t5.vy == t.vy && t5.vz == t.vz;
             if (t.hit) s4 = s4 && memcmp(&t4.pos, &t.pos, 12) == 0 && memcmp(&t4.normal, &t.normal, 12) == 0 && t4.vx == t.vx && t4.vy == t.vy && t4.vz == t.vz;
             if (!s4 && bad2++ < 5)
                 printf("tracer2: ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g): hit %d/%d steps %d/%d pos (%.9g,%.9g,%.9g)/(%.9g,%.9g,%.9g) vox (%d,%d,%d)/(%d,%d,%d)\n", i, o[0], o[1], o[2], d[0], d[1], d[2],

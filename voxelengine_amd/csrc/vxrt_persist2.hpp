@@ -21,6 +21,15 @@ namespace vxrt {
 // of this tracer cost less than half of WaveTracer's while the phases cost about the same, so waiting for more lanes pays:
 // end-of-walk waits until its lanes are as many as the others (N = 1), ray-finished and the tight-box phase (which now
 // also enters the brick) until they are half as many.  Sweep in profiles/r03_variant7.md.
+// What runs between the probe pairs of an iteration: 0 = nothing (default: the pairs run back to back, the walking mask
+// carried in scalar registers); A/B: 1 = tight box, then end of walk, on fresh votes (variant 5's schedule); 2 = the tight box only
+#ifndef VXRT_INNER_CASCADE
+#define VXRT_INNER_CASCADE 0
+#endif
+// probe pairs per loop iteration (between two rounds of votes)
+#ifndef VXRT_SUBROUNDS2
+#define VXRT_SUBROUNDS2 3
+#endif
 #ifndef VXRT_VOTE2_NEXT
 #define VXRT_VOTE2_NEXT 2
 #endif
@@ -422,10 +431,13 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // cascade; with it 1x3 4.18, 1x4 4.21, 2x2 4.31, 2x3 and 2x4 the same, 3x3 4.37, 3x2 4.12 (register allocation),
         // 4x2 falls into scratch.  The same schedule as a rolled loop (vote the ray-finished phase every 2nd or 3rd
         // round of 2 probes) pays the round's four ballots and the loop branch per group: 4.02.
-        for (int g = 0; g < VXRT_SUBROUNDS; ++g) {
-            if (g > 0) {
+#if VXRT_INNER_CASCADE == 0
+        T.probe_pairs<VXRT_SUBROUNDS2>(W);
+#else
+        for (int g = 0; g < VXRT_SUBROUNDS2; ++g) {
+            if (g > 0 && VXRT_INNER_CASCADE != 0) {
                 int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
-                    m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+                    m_e = VXRT_INNER_CASCADE == 2 ? 0 : __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
                 if (vote2(m_b, m_w, VXRT_VOTE2_BOX, VXRT_VOTE2_ABS_BOX)) {
                     if (STATS) {
                         dg_runs[2] += 1u;
@@ -436,10 +448,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                     if (STATS)
                         dg_park_ticks += wall_clock64();
                     m_b = 0;
-                    m_w = __popcll(__ballot(T.st == ST_WALK));
-                    m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+                    if (VXRT_INNER_CASCADE == 1) {
+                        m_w = __popcll(__ballot(T.st == ST_WALK));
+                        m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+                    }
                 }
-                if (vote2(m_e, m_w + m_b, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
+                if (VXRT_INNER_CASCADE == 1 && vote2(m_e, m_w + m_b, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
                     if (STATS) {
                         dg_runs[1] += 1u;
                         dg_lanes[1] += (unsigned)m_e;
@@ -452,6 +466,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             }
             T.probe_group(W);
         }
+#endif
     }
 
     if (lane == 0) {

@@ -498,20 +498,20 @@ struct WaveTracer2 {
         fine_m |= __ballot(go_fine);
     }
 
-    // Two probes.  Per probe: load the occupancy word of idx; advance every walking lane (history, t, then tn / idx / rem
-    // of the chosen axis under that axis' mask); see who left the grid or passed t_hi; when the word arrives, see who
-    // stood on an occupied cell.  The second probe's address does not depend on the first word.
-    __device__ __forceinline__ void step2(const WorldView& W)
+    // PAIRS x two probes without a vote between them.  Per probe: load the occupancy word of idx; advance every walking
+    // lane (history, t, then tn / idx / rem of the chosen axis under that axis' mask); see who left the grid or passed
+    // t_hi; when the word arrives, see who stood on an occupied cell.  The second probe's address of a pair does not depend
+    // on the first word.  The walking mask is carried from probe to probe in scalar registers and `st` is written once,
+    // after the last pair; `fix` can only be set by a phase, i.e. before the first pair.
+    template <int PAIRS>
+    __device__ __forceinline__ void probe_pairs(const WorldView& W)
     {
         (void)W;
 #ifdef VXRT_HOST_CHECK
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < 2 * PAIRS; ++p) {
             if (st != ST_WALK)
                 return;
             const uint32_t i1 = idx;
-#ifdef VXRT_HOST_DEBUG
-            if (i1 > (1u << 26)) { fprintf(stderr, "wild idx %u rem %x rp %x rpp %x fix %u di %d %d %d fine %d tl %g thi %g\n", i1, rem, rp, rpp, fix, (int)di_x, (int)di_y, (int)di_z, (int)lane_fine(), tl, t_hi); abort(); }
-#endif
             const uint32_t word = bits[i1 >> 5];
             const bool a0 = tn_x < tn_y && tn_x < tn_z;
             const bool a1 = !(tn_x < tn_y) && tn_y < tn_z;
@@ -544,26 +544,32 @@ struct WaveTracer2 {
                 st = ST_END;
         }
 #else
-        const lanemask_t w1 = lane_mask(st == ST_WALK);
-        lanemask_t sus1, gd1, sus2, gd2;
-        // ---- probe 1
-        const uint32_t i1 = idx;
-        const uint32_t word1 = bits[i1 >> 5];
-        advance(w1, sus1, gd1);
-        idx -= fix;
-        fix = 0u;
-        // ---- probe 2's load
-        const uint32_t i2 = idx;
-        const uint32_t word2 = bits[i2 >> 5];
-        // ---- probe 1: who stood on an occupied cell
-        const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w1;
-        const lanemask_t stop1 = h1 | sus1 | gd1;
-        const lanemask_t w2 = w1 & ~stop1;
-        advance(w2, sus2, gd2);
-        const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
-        const lanemask_t h = h1 | h2;
-        const lanemask_t other = ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
-        const lanemask_t park = h & ~fine_m, lhit = h & fine_m;
+        lanemask_t w = lane_mask(st == ST_WALK);
+        lanemask_t hits = 0ull, other = 0ull;
+#pragma unroll
+        for (int k = 0; k < PAIRS; ++k) {
+            lanemask_t sus1, gd1, sus2, gd2;
+            // ---- probe 1
+            const uint32_t i1 = idx;
+            const uint32_t word1 = bits[i1 >> 5];
+            advance(w, sus1, gd1);
+            if (k == 0) {
+                idx -= fix;
+                fix = 0u;
+            }
+            // ---- probe 2's load
+            const uint32_t i2 = idx;
+            const uint32_t word2 = bits[i2 >> 5];
+            // ---- probe 1: who stood on an occupied cell
+            const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w;
+            const lanemask_t w2 = w & ~(h1 | sus1 | gd1);
+            advance(w2, sus2, gd2);
+            const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
+            hits |= h1 | h2;
+            other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
+            w = w2 & ~(h2 | sus2 | gd2);
+        }
+        const lanemask_t park = hits & ~fine_m, lhit = hits & fine_m;
         unsigned long long save;
         asm volatile("s_mov_b64 %[save], exec\n\t"
                      "s_mov_b64 exec, %[park]\n\t"
@@ -577,6 +583,7 @@ struct WaveTracer2 {
                      : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
 #endif
     }
+    __device__ __forceinline__ void step2(const WorldView& W) { probe_pairs<1>(W); }
 
 #ifndef VXRT_HOST_CHECK
     // One speculative DDA advance (:293-322) of the lanes in `w`, in place.  Outputs (limited to w): sus = lanes whose t
@@ -659,6 +666,7 @@ struct WaveTracer2 {
 };
 
 // one ray per lane, entered by the whole wave at a converged point (host check and the batch test kernel)
+template <int PAIRS = 1>
 __device__ inline void trace_wave2(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
                                    TraceResult& out, uint32_t* cold_column)
 {
@@ -678,7 +686,7 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
             T.phase_end(W);
         if (vote_run(n_box, n_walk, VXRT_VOTE_BOX))
             T.phase_box(W);
-        T.probe_group(W);
+        T.template probe_pairs<PAIRS>(W);
     }
     if (active)
         T.result(W, out);
