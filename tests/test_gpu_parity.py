@@ -47,7 +47,9 @@ def test_trace_batch_random_worlds(eng, vxo, factor, size, density, seed):
     cpu = w.trace_batch(o, d)
     gpu = ctx.Raytrace(o, d, want_stats=True)
     _assert_batch_equal(gpu, cpu)
+    _assert_batch_equal(ctx.Raytrace(o, d), cpu)      # the timed instantiation
     st = gpu["stats"]
+    assert st.primary_rays == len(o) and st.primary_hits == int(cpu["hit"].sum())
     assert (st.coarse_probes, st.brick_entries, st.fine_probes) == (
         cpu["stats"].coarse_probes, cpu["stats"].brick_entries, cpu["stats"].fine_probes)
     assert 0 < int(cpu["hit"].sum()) < len(o)
@@ -107,11 +109,15 @@ def test_invalid_rays_are_defined_misses_and_a_bad_camera_is_rejected(eng, vxo):
             bad[idx] = True
         good = ~bad
         cpu = w.trace_batch(o[good], d[good])
-        for variant, waves_per_cu in ((2, 1), (2, 0), (1, 0)):   # the queue kernel, one ray per lane, straightforward
+        # the queue kernel, one ray per lane, straightforward -- and the kernels the default and variant 7 take, counting
+        # and as timed (one ray per lane on the second tracer; the default's queue kernel on the small grid)
+        for variant, waves_per_cu, want_stats in ((2, 1, True), (2, 0, True), (1, 0, True), (7, 0, True), (7, 0, False),
+                                                  (4, 0, False), (4, 1, False), (4, 1, True)):
             ctx.set_kernel_variant(variant)
             ctx.set_persistent_waves_per_cu(waves_per_cu)
-            g = ctx.Raytrace(o, d, want_stats=True)
-            assert g["stats"].primary_rays == n
+            g = ctx.Raytrace(o, d, want_stats=want_stats)
+            if want_stats:
+                assert g["stats"].primary_rays == n
             sub = {k: g[k][good] for k in ("hit", "steps", "voxel", "hitPoint", "normal")}
             _assert_batch_equal(sub, cpu)
             assert not g["hit"][bad].any() and not g["steps"][bad].any() and (g["voxel"][bad] == -1).all(), variant
@@ -178,14 +184,22 @@ def test_known_answer_rays_on_gpu(eng, vxo):
         v[p] = True
     w = vxo.World.from_voxels(v, 8)
     _upload(ctx, w)
-    r = ctx.Raytrace([(60.0, 11.5, 11.5)], [(-1, 0, 0)], want_stats=True)
     up = np.nextafter(np.float32(1.4375), np.float32(np.inf))
     yw = np.float32(np.float32(np.float32(up * np.float32(8)) - np.float32(8)) + np.float32(8))
-    assert r["steps"][0] == 13 and r["hit"][0] == 1
-    assert r["hitPoint"][0].tolist() == [19.0, float(yw), float(yw)]
-    assert r["normal"][0].tolist() == [-1, 0, 0]
-    assert r["voxel"][0] == 18 + 64 * (11 + 64 * 11)
-    assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == (6, 2, 10)
+    default = ctx.kernel_variant
+    try:
+        for variant in (4, 7, 2, 1):   # (7: the tracer of the headline kernel, with and without its probe counters)
+            ctx.set_kernel_variant(variant)
+            for want_stats in (True, False):
+                r = ctx.Raytrace([(60.0, 11.5, 11.5)], [(-1, 0, 0)], want_stats=want_stats)
+                assert r["steps"][0] == 13 and r["hit"][0] == 1, variant
+                assert r["hitPoint"][0].tolist() == [19.0, float(yw), float(yw)], variant
+                assert r["normal"][0].tolist() == [-1, 0, 0], variant
+                assert r["voxel"][0] == 18 + 64 * (11 + 64 * 11), variant
+                if want_stats:
+                    assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == (6, 2, 10), variant
+    finally:
+        ctx.set_kernel_variant(default)
 
 
 def test_quirk_cases_on_gpu(eng, vxo):
@@ -201,12 +215,15 @@ def test_quirk_cases_on_gpu(eng, vxo):
             _upload(ctx, w)
             e = case["expect"]
             ctx.set_batch_max_steps(case["max_steps"])
-            for variant in (2, 1):   # (a one-ray batch: 2 = the wave-level tracer, 1 = the straightforward loops)
+            # (a one-ray batch: 7 = the tracer of the headline kernel, with its probe counters and -- `False` -- as timed;
+            # 2 = the first wave-level tracer, 1 = the straightforward loops)
+            for variant, want_stats in ((7, True), (7, False), (4, False), (2, True), (1, True)):
                 ctx.set_kernel_variant(variant)
-                r = ctx.Raytrace([o], [d], want_stats=True)
+                r = ctx.Raytrace([o], [d], want_stats=want_stats)
                 assert bool(r["hit"][0]) == e["hit"] and int(r["steps"][0]) == e["steps"], (name, variant)
                 assert r["normal"][0].tolist() == [float(x) for x in e["normal"]], (name, variant)
-                assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == tuple(e["stats"]), (name, variant)
+                if want_stats:
+                    assert (r["stats"].coarse_probes, r["stats"].brick_entries, r["stats"].fine_probes) == tuple(e["stats"]), (name, variant)
                 if e["hit"]:
                     assert r["hitPoint"][0].tolist() == [float(np.float32(x)) for x in e["pos"]], (name, variant)
                     assert int(r["voxel"][0]) == quirk_cases.voxel_index(e["voxel"], case["size"]), (name, variant)
@@ -309,14 +326,25 @@ def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
     ctx.SetEnvironment(list(p.env.light_dir), list(p.env.light_color), list(p.env.ambient))
     ctx.SetFOV(p.fov_deg)
     ctx.SetOrthoWindowSize(p.ortho_size[0], p.ortho_size[1])
-    opts = vx.RenderOptions(mode=kw.get("mode", 0), checkerboard=bool(kw.get("checkerboard", 0)),
-                            shadow=bool(kw.get("shadow", 0)), bounce_samples=kw.get("bounce_samples", 0),
-                            bounce_all_hits=bool(kw.get("bounce_all_hits", 0)), ortho=bool(kw.get("ortho", 0)),
-                            bounce_depth=kw.get("bounce_depth", 1),
-                            frame_number=frame_number, collect_stats=True)
+    okw = dict(mode=kw.get("mode", 0), checkerboard=bool(kw.get("checkerboard", 0)),
+               shadow=bool(kw.get("shadow", 0)), bounce_samples=kw.get("bounce_samples", 0),
+               bounce_all_hits=bool(kw.get("bounce_all_hits", 0)), ortho=bool(kw.get("ortho", 0)),
+               bounce_depth=kw.get("bounce_depth", 1), frame_number=frame_number)
+    # The frame, the colour AOV and the hit indices that are compared with the oracle come from the TIMED instantiation of
+    # the kernel (no probe counting), and the kernel is the one the test names: a forced variant must not be swapped.
+    opts = vx.RenderOptions(**okw)
+    if ctx.kernel_variant != 4:
+        assert ctx.kernel_for_launch(W, H, opts) == ctx.kernel_variant
     ctx.frame_stats()   # counters accumulate until read: start this frame from zero
     ctx.RenderScreen(W, H, d_fb, pos, f, u, r, opts, color_aov=d_col, hit_aov=d_hit)
+    plain = ctx.frame_stats()
+    # ... and a second launch of the probe-counting instantiation of the same kernel gives the counters (and the same frame)
+    d_fb2 = torch.from_numpy(fb0.copy()).cuda()
+    ctx.RenderScreen(W, H, d_fb2, pos, f, u, r, vx.RenderOptions(collect_stats=True, **okw))
     st = ctx.frame_stats()
+    assert torch.equal(d_fb2, d_fb)
+    assert (plain.primary_rays, plain.shadow_rays, plain.bounce_rays, plain.primary_hits) == (
+        st.primary_rays, st.shadow_rays, st.bounce_rays, st.primary_hits)
     return cpu, d_fb.cpu().numpy(), d_col.cpu().numpy(), d_hit.cpu().numpy(), st
 
 

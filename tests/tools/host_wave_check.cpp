@@ -85,16 +85,21 @@ int main(int argc, char** argv)
         // the tracer built for the vector pipe's two instruction classes (vxrt_wave2.hpp): same results
         if (tracer2_fits(W)) {
             TraceResult t4{};
-            trace_wave2(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column);
+            RayCounters c4{0, 0, 0}, c5{0, 0, 0};
+            trace_wave2<1, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
             // ... and with three probe pairs between two rounds of votes, as k_render_persist2 runs it
             TraceResult t5{};
-            trace_wave2<3>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column);
+            trace_wave2<3, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
             bool s4 = t4.hit == t.hit && t4.steps == t.steps && t5.hit == t.hit && t5.steps == t.steps;
+            // the probe counters this tracer derives from its packed step counters at the end of each walk: the oracle's
+            s4 = s4 && c4.coarse_probes == st.coarse_probes && c4.brick_entries == st.brick_entries && c4.fine_probes == st.fine_probes;
+            s4 = s4 && c5.coarse_probes == st.coarse_probes && c5.brick_entries == st.brick_entries && c5.fine_probes == st.fine_probes;
             if (t.hit) s4 = s4 && memcmp(&t5.pos, &t.pos, 12) == 0 && memcmp(&t5.normal, &t.normal, 12) == 0 && t5.vx == t.vx && t5.vy == t.vy && t5.vz == t.vz;
             if (t.hit) s4 = s4 && memcmp(&t4.pos, &t.pos, 12) == 0 && memcmp(&t4.normal, &t.normal, 12) == 0 && t4.vx == t.vx && t4.vy == t.vy && t4.vz == t.vz;
             if (!s4 && bad2++ < 5)
-                printf("tracer2: ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g): hit %d/%d steps %d/%d pos (%.9g,%.9g,%.9g)/(%.9g,%.9g,%.9g) vox (%d,%d,%d)/(%d,%d,%d)\n", i, o[0], o[1], o[2], d[0], d[1], d[2],
-                       t4.hit, t.hit, t4.steps, t.steps, t4.pos.x, t4.pos.y, t4.pos.z, t.pos.x, t.pos.y, t.pos.z, t4.vx, t4.vy, t4.vz, t.vx, t.vy, t.vz);
+                printf("tracer2: ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g): hit %d/%d steps %d/%d pos (%.9g,%.9g,%.9g)/(%.9g,%.9g,%.9g) vox (%d,%d,%d)/(%d,%d,%d) probes %u/%u/%u vs %llu/%llu/%llu\n", i, o[0], o[1], o[2], d[0], d[1], d[2],
+                       t4.hit, t.hit, t4.steps, t.steps, t4.pos.x, t4.pos.y, t4.pos.z, t.pos.x, t.pos.y, t.pos.z, t4.vx, t4.vy, t4.vz, t.vx, t.vy, t.vz,
+                       c4.coarse_probes, c4.brick_entries, c4.fine_probes, (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries, (unsigned long long)st.fine_probes);
             same2 = same2 && s4;
         }
         bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries && c.fine_probes == st.fine_probes;

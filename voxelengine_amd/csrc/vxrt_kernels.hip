@@ -579,6 +579,7 @@ namespace vxrt {
 
 // The batch query on the tracer of vxrt_wave2.hpp (kernel variant 7): one ray per lane, the tracer's cold fields in LDS.
 // It exists so that the batch tests and the randomised parity runs reach that tracer with caller-made rays.
+template <bool STATS>
 __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
 {
     __shared__ uint32_t cold_block[4][CF_TRACER_FIELDS * 64];
@@ -593,7 +594,8 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
     t.pos = t.normal = mk3(0, 0, 0);
     t.vx = t.vy = t.vz = 0;
     t.ncode = 0u;
-    trace_wave2(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63]);
+    RayCounters cnt{0u, 0u, 0u};
+    trace_wave2<1, STATS>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63], &cnt);
     if (live) {
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
         B.pos[3 * i] = p.x;
@@ -608,6 +610,17 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
         if (B.voxel)
             B.voxel[i] = t.hit ? (long long)t.vx + (long long)B.W.X * ((long long)t.vy + (long long)B.W.Y * (long long)t.vz)
                                : -1ll;
+    }
+    if (STATS && B.stats) {
+        const unsigned long long r = wave_sum(live ? 1u : 0u), h = wave_sum(live && t.hit ? 1u : 0u), p0 = wave_sum(cnt.coarse_probes),
+                                 p1 = wave_sum(cnt.brick_entries), p2 = wave_sum(cnt.fine_probes);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&B.stats[kStatPrimary], r);
+            atomicAdd(&B.stats[kStatPrimaryHits], h);
+            atomicAdd(&B.stats[kStatCoarseProbes], p0);
+            atomicAdd(&B.stats[kStatBrickEntries], p1);
+            atomicAdd(&B.stats[kStatFineProbes], p2);
+        }
     }
 }
 
@@ -733,13 +746,6 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
             return launch_render_ts(A, *ts, stats, stream);
         variant = 5;  // (no workspace was leased: cannot happen through vxrt_api.hip)
     }
-    if (variant == 7 && stats) {
-#ifdef VXRT_EXPERIMENTS
-        static const bool diag2 = getenv("VXRT_DIAG2") != nullptr;  // loop diagnostics of the variant-7 kernel itself
-        if (!diag2)
-#endif
-            variant = 5;  // the tracer of vxrt_wave2.hpp counts no probes: the counting launch runs the round-2 kernel
-    }
     if (variant == 2 || variant == 3 || variant == 5 || variant == 7) {
         const unsigned long long ntiles =
             (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
@@ -815,8 +821,11 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
     // size), and what every persistent variant but 2 takes for batches too small for the queue -- BASELINE configs[0]'s
     // million-ray fan: 17.7 Grays/s against 14.0 for k_trace_batch_wave and 16.6 for the straightforward loops
     // (tools/batch_probe.py).  Variant 2 keeps the first tracer (tests and randomised parity run both).
-    if ((variant == 7 || (variant >= 3 && !persistent)) && !stats && !B.dbg_trace && tracer2_fits(B.W)) {
-        hipLaunchKernelGGL(k_trace_batch_wave2, grid, block, 0, stream, B);
+    if ((variant == 7 || (variant >= 3 && !persistent)) && !B.dbg_trace && tracer2_fits(B.W)) {
+        if (stats)
+            hipLaunchKernelGGL(k_trace_batch_wave2<true>, grid, block, 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_trace_batch_wave2<false>, grid, block, 0, stream, B);
         return hipSuccess;
     }
     if (persistent) {

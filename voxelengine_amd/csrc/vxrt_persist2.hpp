@@ -4,9 +4,8 @@
 // state in the wave's LDS block -- with the traversal replaced by WaveTracer2: speculative exec-masked DDA advance, packed
 // step counters instead of cell coordinates, no crossing point in the probe (profiles/r03_instr_cost.md: the vector ALU
 // pipe is what bounds these kernels, and a probe pair of the old tracer is 373 cycles of it, of the new one ~165).
-// The STATS instantiation collects the loop diagnostics only (this tracer counts no probes): launches that collect
-// statistics run k_render_persist_lds<true, ...>, which counts the same probes (the tests hold the two tracers' frames
-// equal), unless the experiments build is told otherwise (VXRT_DIAG2).
+// The STATS instantiation counts the probes of SURVEY 8(d) (WaveTracer2 derives them from its packed step counters at the
+// end of each walk, so the probes themselves are the timed kernel's) and collects the loop diagnostics.
 #pragma once
 
 #include "vxrt_persist_lds.hpp"
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         return LaneView{A.origin, A.fwd, A.up, A.right, A.frame_number, A.fb, A.color_aov, A.hit_aov};
     };
 
-    WaveTracer2 T;  // (STATS: the loop diagnostics only; this tracer counts no probes)
+    WaveTracer2 T;
     T.init(W, &cold_block[lane]);  // st = ST_DONE: every lane starts by asking for a pixel
     uint32_t stage = PX_NONE;
     uint32_t px_tx = 0, px_row = 0;
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[2] += (unsigned)c_box;
                 dg_park_ticks -= wall_clock64();
             }
-            T.phase_box(W);
+            T.phase_box<STATS>(W);
             if (STATS)
                 dg_park_ticks += wall_clock64();
             c_box = 0;
@@ -184,7 +183,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[1] += (unsigned)c_end;
                 dg_park_ticks -= wall_clock64();
             }
-            T.phase_end(W);
+            T.phase_end<STATS>(W);
             if (STATS)
                 dg_park_ticks += wall_clock64();
             c_end = 0;
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                         dg_lanes[2] += (unsigned)m_b;
                         dg_park_ticks -= wall_clock64();
                     }
-                    T.phase_box(W);
+                    T.phase_box<STATS>(W);
                     if (STATS)
                         dg_park_ticks += wall_clock64();
                     m_b = 0;
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                         dg_lanes[1] += (unsigned)m_e;
                         dg_park_ticks -= wall_clock64();
                     }
-                    T.phase_end(W);
+                    T.phase_end<STATS>(W);
                     if (STATS)
                         dg_park_ticks += wall_clock64();
                 }
@@ -484,7 +483,11 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         atomicAdd(&A_kern.stats[kStatPrimaryHits], s3);
     }
     if (STATS) {
+        const unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries), p2 = wave_sum(T.cnt.fine_probes);
         if (lane == 0 && A_kern.stats) {
+            atomicAdd(&A_kern.stats[kStatCoarseProbes], p0);
+            atomicAdd(&A_kern.stats[kStatBrickEntries], p1);
+            atomicAdd(&A_kern.stats[kStatFineProbes], p2);
             atomicAdd(&A_kern.stats[kStatDbgIters], dg_iters);
             atomicAdd(&A_kern.stats[kStatDbgWalkLanes], dg_walk);
             atomicAdd(&A_kern.stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);

@@ -96,6 +96,11 @@ struct WaveTracer2 {
     f3 point;                 // HitIntersectedPoint of the walk that ended (tight-box phase / end-of-walk phase)
     lanemask_t fine_m;        // wave mask: lanes walking inside a brick
     uint32_t* cold;           // &block[lane]; field F of this lane is cold[F * 64] (CF_* of vxrt_wave.hpp)
+    // Probe counters of SURVEY 8(d)'s algorithmic bytes (the STATS instantiations of the phases only; dead otherwise):
+    // in-range coarse probes (:247-256), brick entries (:420), in-range brick probes (:276).  They fall out of the walk's
+    // packed step counters when the walk ends -- a walk that ends after k advances has probed k + 1 cells -- so the probes
+    // themselves count nothing.
+    RayCounters cnt;
 
     __device__ __forceinline__ bool lane_fine() const
     {
@@ -125,6 +130,7 @@ struct WaveTracer2 {
         ws = point = mk3(0, 0, 0);
         rem0 = 0u;
         fine_m = 0ull;
+        cnt = RayCounters{0u, 0u, 0u};
     }
 
     // slab test against [bmin,bmax] from point s with the hoisted reciprocals (RayIntersectsAABB, :124-174)
@@ -334,6 +340,7 @@ struct WaveTracer2 {
     // (the last advance left the grid and / or was later than t_hi, or the walk never started) and ST_ENDHIT (a brick walk
     // whose probe found an occupied voxel).  Coarse walks that end on a hit tight box never come here: the tight-box
     // phase enters the brick itself.
+    template <bool STATS = false>
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
         const bool me = st == ST_END || st == ST_ENDHIT;
@@ -366,6 +373,13 @@ struct WaveTracer2 {
                 const bool last_counts = !hit && stepped && !region_fail;
                 const uint32_t steps = rem0 - rem_sum(rp) + (last_counts ? 1u : 0u);
                 const uint32_t dec_c = last_counts ? dec_last : dec_prev;  // the last counted step's axis
+                if (STATS) {
+                    // every iteration of the walk up to the cell `rp` was in range and probed its cell (:240-280): the start
+                    // cell plus one per advance before rp; a walk that never started (start outside the grid) probed nothing
+                    const uint32_t probed = (hit || stepped) ? rem0 - rem_sum(rp) + 1u : 0u;
+                    cnt.fine_probes += is_fine ? probed : 0u;
+                    cnt.coarse_probes += is_fine ? 0u : probed;
+                }
                 f3 pc = cr;
                 if (!last_counts)
                     pc = cross_of(W, is_fine, rpp, dec_prev, tp);
@@ -437,6 +451,7 @@ struct WaveTracer2 {
 
     // parked phase: tight-box test of an occupied coarse cell (:248-273) and, on a hit, the end of the coarse walk with
     // the entry into the cell's brick (:395-429).  Called by the whole wave; works on st == ST_BOX.
+    template <bool STATS = false>
     __device__ __forceinline__ void phase_box(const WorldView& W)
     {
         bool go_fine = false;
@@ -463,6 +478,8 @@ struct WaveTracer2 {
                 // the coarse walk ends here (:395-407): its steps, its HitIntersectedPoint (`step != 0`, :266)
                 const uint32_t steps = rem0 - rem_sum(rp);
                 cold[CF_TOTAL * 64] += steps;
+                if (STATS)
+                    cnt.coarse_probes += steps + 1u;  // the start cell and one cell per step, the hit cell included
                 point.x = steps != 0u ? bp.x : ws.x;
                 point.y = steps != 0u ? bp.y : ws.y;
                 point.z = steps != 0u ? bp.z : ws.z;
@@ -473,6 +490,8 @@ struct WaveTracer2 {
                     const uint32_t dec = rp - rem;
                     const int axis = dec == kRemDecX ? 0 : (dec == kRemDecY ? 1 : 2);
                     const int packed = axis | ((x - qx) << 2) | ((y - qy) << 3) | ((z - qz) << 4);
+                    if (STATS)
+                        cnt.brick_entries += 1u;  // the descriptor load of :419-420
                     cold[CF_LAST_CI * 64] = ci;
                     cold[CF_CHX * 64] = (uint32_t)qx;
                     cold[CF_CHY * 64] = (uint32_t)qy;
@@ -666,9 +685,9 @@ struct WaveTracer2 {
 };
 
 // one ray per lane, entered by the whole wave at a converged point (host check and the batch test kernel)
-template <int PAIRS = 1>
+template <int PAIRS = 1, bool STATS = false>
 __device__ inline void trace_wave2(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
-                                   TraceResult& out, uint32_t* cold_column)
+                                   TraceResult& out, uint32_t* cold_column, RayCounters* counters = nullptr)
 {
     WaveTracer2 T;
     T.init(W, cold_column);
@@ -683,13 +702,18 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
         if (vote_run(n_end, n_walk + n_box, VXRT_VOTE_END))
-            T.phase_end(W);
+            T.template phase_end<STATS>(W);
         if (vote_run(n_box, n_walk, VXRT_VOTE_BOX))
-            T.phase_box(W);
+            T.template phase_box<STATS>(W);
         T.template probe_pairs<PAIRS>(W);
     }
     if (active)
         T.result(W, out);
+    if (STATS && counters) {
+        counters->coarse_probes += T.cnt.coarse_probes;
+        counters->brick_entries += T.cnt.brick_entries;
+        counters->fine_probes += T.cnt.fine_probes;
+    }
 }
 
 }  // namespace vxrt
