@@ -64,9 +64,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=48, help="frames of the workload timed on the host cores")
     ap.add_argument("--views-per-step", type=int, default=16,
                     help="views rendered by one launch (vxrt_render_views); 1 = one RenderScreen-style launch per frame")
-    ap.add_argument("--kernel-variant", type=int, default=4, choices=[1, 2, 4, 5, 6, 7],
-                    help="render kernel (vxrt_set_kernel_variant): 4 = the library's per-launch policy (default); 6 = the "
-                         "traversal / shading pipeline; for A/B runs")
+    ap.add_argument("--kernel-variant", type=int, default=4, choices=[1, 4, 7],
+                    help="render kernel (vxrt_set_kernel_variant): 4 = default (= 7, the persistent kernel on the wave-level "
+                         "tracer); 1 = the straightforward per-lane loops (cross-check)")
     ap.add_argument("--bounce-all-hits", type=int, default=0)
     ap.add_argument("--bounce-depth", type=int, default=1, help="2 = second bounce (BASELINE config 5; extension beyond the reference)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -329,9 +329,11 @@ def run(args):
         kernel_id = ctx.kernel_for_launch(W, H, opts(), V if V > 1 else 0)
         kernel_symbol = "%s<false,%s,%s>" % (ctx.KERNEL_NAMES[kernel_id], "true" if args.bounce_depth == 2 else "false",
                                              "true" if V > 1 else "false")
-        if kernel_id == 6:  # the traversal / shading pipeline: the step's launch time covers k_ts_gen + per generation T and S
-            kernel_symbol = "k_ts_trace<false> (+ k_ts_gen, k_ts_shade<%s>: one T and one S launch per ray generation)" % (
-                "true" if args.bounce_depth == 2 else "false")
+        if kernel_id == 1:
+            kernel_symbol = "k_render<false>"
+        # the counting pass above ran the STATS instantiation of the same kernel (it derives the probe counts from the
+        # tracer's own step counters; no other kernel stands in for it)
+        count_symbol = kernel_symbol.replace("<false", "<true", 1)
         tj = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tj) and world == 1:
             try:
@@ -368,6 +370,7 @@ def run(args):
                 "world_build_s": round(t_build, 2), "bricks": int(info.nslots), "world_hbm_gib": round(info.hbm_bytes / 2**30, 3),
             },
             "roofline": {"bound": "hbm (algorithmic-bytes convention)", "kernel": kernel_symbol,  # the library's choice
+                         "probe_count_kernel": count_symbol, "fallback": None,  # (no launch shape or world takes another kernel)
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(bytes_total / n_launch, 1),

@@ -45,32 +45,21 @@ int vxrt_destroy(vxrt_ctx *ctx);
 /* message of the last failing call on this thread (never NULL) */
 const char *vxrt_last_error(void);
 int vxrt_synchronize(vxrt_ctx *ctx);
-/* kernel implementation used by vxrt_render / vxrt_render_views (and vxrt_trace_batch).  All give identical results.
- *   4 (default) = persistent waves, the kernel picked per launch from measurements: 7 (5 for a world 7 does not fit)
- *       for a launch over several views and for a large single-view launch (at least 4 M rays, counting one shadow and
- *       one bounce ray per pixel where enabled), 2 for a small one;
- *   2 = persistent waves, one pixel chain per lane, pixels from a tile queue;
- *   5 = 2 with the state only the parked phases touch in LDS: 96 VGPRs, 5 waves per SIMD;
- *   6 = wavefront pipeline: a traversal kernel and a shading kernel that hand each other prepared ray records through HBM,
- *       generation by generation (primary, shadow, bounce): measured 5 % behind 5 on 16-view launches, 40 % behind on one
- *       view.  Its queues live in a workspace of 178 bytes per pixel of the launch (186 with a hit-index
- *       AOV), taken from a ring of three per context: a fourth variant-6 launch in flight waits for the oldest; the first
- *       launch of a shape allocates, so it cannot happen inside a stream capture;
- *   7 = 5 on the tracer of csrc/vxrt_wave2.hpp (round 3): the DDA advance speculative and exec-masked, the cell as a bit
- *       index + three packed step counters, the region check by a threshold in the probe and exactly at the end of a
- *       walk, brick entry inside the tight-box phase.  What 4 picks for multi-view and large launches; needs a coarse grid
- *       of at most 1022 x 510 x 1022 cells whose dimensions sum to less than 2044 (else the launch runs 5);
- *   1 = straightforward per-lane loops (the on-device cross-check).
- * Variants 0 (wave-level state machine, one lane per pixel) and 3 (pixel chains pooled in LDS) are A/B kernels of the
- * experiments build (libvxrt_exp.so) and are refused by the product library.  (Batch traces: 1 = straightforward,
- * 0 = the wave-level tracer, 7 = the tracer of vxrt_wave2.hpp one ray per lane; anything else: the wave-level tracer behind a
- * persistent ray queue for batches of at least 8 rays per lane of the persistent grid, and below that one ray per lane -- on the
- * tracer of vxrt_wave2.hpp (4, 5, 6; worlds it fits, no statistics requested) or on the first tracer (2).) */
+/* kernel implementation used by vxrt_render / vxrt_render_views and vxrt_trace_batch.  Both give identical results.
+ *   7 = the product kernels, all on the wave-level tracer of csrc/vxrt_wave2.hpp: k_render_persist2 (persistent
+ *       wavefronts, one pixel chain per lane, pixels from a tile queue, the state only the parked phases touch in LDS:
+ *       96 VGPRs, 5 waves per SIMD) for every render launch, whatever its size and the world's; for batches
+ *       k_trace_batch_persist (a persistent ray queue) from 8 rays per lane of the persistent grid upwards and
+ *       k_trace_batch_wave2 (one ray per lane) below that;
+ *   4 (default) = 7;
+ *   1 = straightforward per-lane loops (k_render, k_trace_batch): the on-device cross-check.
+ * Any other value is refused (rounds 1-3 carried further kernels under 0, 2, 3, 5 and 6; profiles/ keeps their
+ * measurements). */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
-/* 1 when the library was built with -DVXRT_EXPERIMENTS (variants 0 and 3, development knobs read from the environment) */
+/* 1 when the library was built with -DVXRT_EXPERIMENTS (development knobs read from the environment; A/B builds) */
 int vxrt_has_experiments(void);
 /* Size of the persistent kernels' grid, in wavefronts per compute unit at 4 waves per SIMD (default 16 = 4 per SIMD; the
- * 5- and 6-wave kernels scale it).  For tests that need a small grid (a batch then takes the queue kernel at a few
+ * kernels, built for 5 waves per SIMD, scale it by 5/4).  For tests that need a small grid (a batch then takes the queue kernel at a few
  * thousand rays) and for occupancy measurements; 0 restores the default. */
 int vxrt_set_persistent_waves_per_cu(vxrt_ctx *ctx, int waves_per_cu);
 
@@ -133,7 +122,7 @@ int vxrt_download_world(vxrt_ctx *ctx, uint32_t *coarse_bits, uint32_t *brick_sl
  * in the order of coarse_bits, and the pool.  Loading validates sizes, sums and the cell table against the coarse
  * bits, and streams through a 64 MiB staging buffer.  Version 1 files (104-byte header, plain word sums only; written
  * by the first round's builds) are refused: regenerate them with vxrt_save_world.  Shapes: every coarse dimension a
- * positive multiple of 8, at most 65535, with cx * cz < 2^24 and cx * cy * cz < 2^32 (32-bit cell indices). */
+ * positive multiple of 8, at most 65535, with cy * cz < 2^24 and cx * cz * (cy + 2) < 2^32 (32-bit cell indices). */
 int vxrt_save_world(vxrt_ctx *ctx, const char *path);
 int vxrt_load_world(vxrt_ctx *ctx, const char *path);
 /* header of a brickmap file (no GPU needed); hbm_bytes = bytes the three streams will occupy */
@@ -211,7 +200,7 @@ typedef struct vxrt_render_flags {
      * shard s % strip_count.  strip_count <= 1 renders the whole frame. */
     int32_t strip_rows, strip_count, strip_index;
     int32_t compact;         /* 1: d_fb (and AOVs) hold only this shard's strips, packed in order */
-    int32_t collect_stats;   /* 1: also count probes (slower kernel variant); rays are always counted */
+    int32_t collect_stats;   /* 1: also count probes (the STATS instantiation of the same kernel); rays are always counted */
     int32_t tile_schedule;   /* persistent kernel: 1 (default) = hand out the rows of 8x8 pixel tiles expected-longest
                                 first (ranked per frame on the host by the elevation of the row's centre ray in a
                                 Y-up world); 0 = row-major.  Scheduling only: results do not depend on it */
@@ -257,7 +246,7 @@ typedef struct vxrt_view {
 } vxrt_view;
 int vxrt_render_views(vxrt_ctx *ctx, uint32_t width, uint32_t height, uint32_t n_views, const vxrt_view *views,
                       const vxrt_render_flags *flags);
-/* the kernel (0, 1, 2, 3 or 5) a vxrt_render (nviews = 0) or vxrt_render_views launch of this shape would run under the
+/* the kernel (7 or 1) a vxrt_render (nviews = 0) or vxrt_render_views launch of this shape would run under the
  * context's current variant; -1 on bad arguments.  For tools that label measurements by kernel (bench.py). */
 int vxrt_kernel_for_launch(const vxrt_ctx *ctx, uint32_t width, uint32_t height, const vxrt_render_flags *flags, uint32_t nviews);
 /* number of frame rows owned by a shard, = rows of its compact buffer */
@@ -266,11 +255,6 @@ uint32_t vxrt_compact_rows(uint32_t height, int32_t strip_rows, int32_t strip_co
  * the device (every stream).  The device-side counters only grow: "since the previous read" is a host-side snapshot, so a
  * read never clears memory that a running kernel adds to. */
 int vxrt_frame_stats_get(vxrt_ctx *ctx, vxrt_frame_stats *out);
-/* Diagnostics of the experiments build (libvxrt_exp.so; zeros from the product library): histogram over the wave-loop
- * iterations of probe-counting launches (collect_stats) since the previous read -- out[n] = iterations in which the lanes of
- * a wavefront that were walking inside a brick sat in n DISTINCT bricks, n = 0..64; out[65 + n] = the same count over the
- * iterations in which no lane walked on the coarse grid (profiles/r03_mechanisms_ab.md). */
-int vxrt_debug_brick_histogram(vxrt_ctx *ctx, uint64_t out[130]);
 /* scatter `strip_count` compact shard buffers (laid out back to back, shard-major, each padded to
  * `shard_stride_bytes`) into a full W*H BGRA8 frame on the device; used by the root after the gather. */
 int vxrt_deinterleave_strips(vxrt_ctx *ctx, uint32_t width, uint32_t height, int32_t strip_rows,

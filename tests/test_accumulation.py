@@ -73,7 +73,7 @@ def test_accumulation_reduces_frame_to_frame_noise(vxo):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [4, 2, 5, 6, 7, 1])
+@pytest.mark.parametrize("variant", [4, 1])
 def test_gpu_accumulation_equals_the_oracle(vxo, variant):
     import torch
     import voxelengine_amd as vx

@@ -92,7 +92,7 @@ def test_hip_million_ray_batch(vxo, case):
     ctx = vx.Context(0)
     try:
         ctx.upload_world(w.factor, w.cdims, w.coarse_bits, w.brick_slot, w.bounds, w.pool)
-        for variant in (2, 1):
+        for variant in (4, 1):
             ctx.set_kernel_variant(variant)
             _check_against_fixture(ctx.Raytrace(o, d), g, "hitPoint")
         # the same world built on the device

@@ -84,8 +84,8 @@ def test_trace_batch_persistent_queue(eng, vxo, n):
 def test_invalid_rays_are_defined_misses_and_a_bad_camera_is_rejected(eng, vxo):
     """Ray validity at the C ABI (include/vxrt.h): a ray with a NaN / infinite component, the zero direction, or a
     direction whose squared length leaves the binary32 range is not traced; its result is a miss with 0 steps.  The valid
-    rays around it are unaffected (equal to the oracle), in every batch kernel -- straightforward, wave state machine and
-    the persistent queue.  A camera with a non-finite component is an error, not a frame."""
+    rays around it are unaffected (equal to the oracle), in every batch kernel -- the persistent queue, one ray per lane,
+    the straightforward loops.  A camera with a non-finite component is an error, not a frame."""
     import os
     vx, ctx0, torch = eng
     ctx = vx.Context(0)
@@ -109,10 +109,9 @@ def test_invalid_rays_are_defined_misses_and_a_bad_camera_is_rejected(eng, vxo):
             bad[idx] = True
         good = ~bad
         cpu = w.trace_batch(o[good], d[good])
-        # the queue kernel, one ray per lane, straightforward -- and the kernels the default and variant 7 take, counting
-        # and as timed (one ray per lane on the second tracer; the default's queue kernel on the small grid)
-        for variant, waves_per_cu, want_stats in ((2, 1, True), (2, 0, True), (1, 0, True), (7, 0, True), (7, 0, False),
-                                                  (4, 0, False), (4, 1, False), (4, 1, True)):
+        # the queue kernel (small persistent grid) and one ray per lane, each counting probes and as timed; the
+        # straightforward loops
+        for variant, waves_per_cu, want_stats in ((4, 1, True), (4, 1, False), (4, 0, True), (4, 0, False), (1, 0, True)):
             ctx.set_kernel_variant(variant)
             ctx.set_persistent_waves_per_cu(waves_per_cu)
             g = ctx.Raytrace(o, d, want_stats=want_stats)
@@ -149,12 +148,12 @@ def test_trace_batch_terrain_and_empty_inputs(eng, vxo):
     _assert_batch_equal(ctx.Raytrace(o[:1], d[:1]), w.trace_batch(o[:1], d[:1]))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 5, 6, 7])
+@pytest.mark.parametrize("variant", [1, 7])
 def test_every_kernel_variant_agrees_with_the_oracle(eng, vxo, variant):
-    """Variants: 1 straightforward per-lane loops, 2 persistent waves with a pixel queue, 5 the same with its cold state
-    in LDS, 6 the traversal / shading pipeline over ray queues, 7 = 5 on the tracer of vxrt_wave2.hpp (speculative
-    exec-masked advance, packed step counters; the default for large launches).  All give the oracle's bits, in every
-    render mode.  (Batch traces: 1 straightforward, 7 the second tracer one ray per lane, anything else the first.)"""
+    """Variants: 7 = the product kernels (persistent wavefronts on the tracer of vxrt_wave2.hpp: speculative exec-masked
+    advance, packed step counters; what the default runs), 1 = the straightforward per-lane loops.  Both give the oracle's
+    bits, in every render mode -- frame, colour AOV and hit indices from the timed instantiation, probe counters from the
+    counting one (_render_both)."""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
@@ -188,7 +187,7 @@ def test_known_answer_rays_on_gpu(eng, vxo):
     yw = np.float32(np.float32(np.float32(up * np.float32(8)) - np.float32(8)) + np.float32(8))
     default = ctx.kernel_variant
     try:
-        for variant in (4, 7, 2, 1):   # (7: the tracer of the headline kernel, with and without its probe counters)
+        for variant in (4, 7, 1):   # (the tracer of the headline kernel, with and without its probe counters; the loops)
             ctx.set_kernel_variant(variant)
             for want_stats in (True, False):
                 r = ctx.Raytrace([(60.0, 11.5, 11.5)], [(-1, 0, 0)], want_stats=want_stats)
@@ -216,8 +215,8 @@ def test_quirk_cases_on_gpu(eng, vxo):
             e = case["expect"]
             ctx.set_batch_max_steps(case["max_steps"])
             # (a one-ray batch: 7 = the tracer of the headline kernel, with its probe counters and -- `False` -- as timed;
-            # 2 = the first wave-level tracer, 1 = the straightforward loops)
-            for variant, want_stats in ((7, True), (7, False), (4, False), (2, True), (1, True)):
+            # 1 = the straightforward loops)
+            for variant, want_stats in ((7, True), (7, False), (4, False), (1, True)):
                 ctx.set_kernel_variant(variant)
                 r = ctx.Raytrace([o], [d], want_stats=want_stats)
                 assert bool(r["hit"][0]) == e["hit"] and int(r["steps"][0]) == e["steps"], (name, variant)
@@ -262,19 +261,15 @@ def test_batch_max_steps_matches_the_oracle(eng, vxo):
         small.close()
 
 
-@pytest.mark.parametrize("variant", [4, 6])
 @pytest.mark.parametrize("depth", [1, 2])
-def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth, variant):
+def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth):
     """More launches in flight than the context has queue heads (64 single-view, 16 multi-view): launch 65 waits for launch 1
     instead of sharing its tile counter (vxrt_api.hip ring_acquire).  80 single-view launches and 20 multi-view launches
     over 4 streams, no synchronisation in between; every frame must be the frame a lone launch renders, and the ray
-    counters must add up.  depth 2 = the second-bounce instantiation of the kernels (the one with the most private state).
-    variant 6 = the traversal / shading pipeline, whose ray queues come from a ring of THREE workspaces per context: launch 4
-    waits for launch 1, and the multi-view launches behind the single-view ones make every ring entry grow."""
+    counters must add up.  depth 2 = the second-bounce instantiation of the kernels (the one with the most private state)."""
     vx, ctx, torch = eng
     w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
     _upload(ctx, w)
-    ctx.set_kernel_variant(variant)
     W, H = 200, 120
     cams = [helpers.camera(c, w.dims, vxo) for c in "ABCD"]
     inv = float(np.float32(1.0) / np.sqrt(np.float32(3.0)))
@@ -311,7 +306,6 @@ def test_eighty_launches_in_flight_over_four_streams(eng, vxo, depth, variant):
     for k in range(20):
         for j in range(4):
             assert torch.equal(mv[k, j], ref[j]), (k, j)
-    ctx.set_kernel_variant(4)
 
 
 def _render_both(eng, vxo, w, W, H, cam, frame_number=1, **kw):
@@ -504,7 +498,7 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("variant", [2, 4, 5, 6, 7, 1])
+@pytest.mark.parametrize("variant", [4, 1])
 def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
     """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).
     Every view must be byte for byte the frame RenderScreen produces for it -- frame, hit-index AOV and colour AOV --
@@ -658,55 +652,72 @@ def test_errors_are_reported_not_swallowed(eng, vxo):
     c2.close()
 
 
-def test_world_too_wide_for_the_second_tracer_runs_the_first(eng, vxo):
-    """Variant 7 packs the steps left to the coarse grid's faces into 11 + 10 + 11 bits: a coarse grid of 1024 cells along x
-    does not fit, the policy (and a forced 7) falls back to 5, and the frame is the oracle's all the same."""
+@pytest.mark.parametrize("cells_x,density", [(8192, 0.000004), (2048, 0.00005), (1024, 0.00003)])
+def test_wide_grids_run_the_product_kernels(eng, vxo, cells_x, density):
+    """Coarse grids beyond the packed step counters of the tracer (11-bit fields: 1022 cells) and long enough for a single
+    walk to reach DDARayTraversal's MAX_STEPS (VolumeRaytracer.cuh:235): 8192, 2048 and 1024 cells along x at f = 8.  The
+    product kernels run them (no fallback): rays along the long axis -- walks of thousands of cells, the counters re-armed
+    on the way, rays that end after 2048 steps of one walk without a hit -- through the queue kernel, one ray per lane and
+    the straightforward loops, probe counters included; and frames through the persistent render kernel."""
     vx, ctx, torch = eng
-    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 8192, 64, 64, 8)
+    X = cells_x * 8
+    rng = np.random.default_rng(cells_x)
+    v = np.zeros((X, 64, 64), bool)
+    n_vox = int(X * 64 * 64 * density)
+    v[rng.integers(0, X, n_vox), rng.integers(0, 64, n_vox), rng.integers(0, 64, n_vox)] = True
+    v[:, 0, :] = True                  # a floor, so that frames have something to shade
+    w = vxo.World.from_voxels(v, 8)
+    assert w.cdims[0] == cells_x
     _upload(ctx, w)
-    default = ctx.kernel_variant
+    n = 60000
+    o, d = helpers.mixed_rays(w.dims, n, cells_x)
+    d[::2, 1:] *= np.float32(0.002)    # half of the rays nearly along the long axis
+    d[::2, 1] = np.abs(d[::2, 1])      # ... and not into the floor
+    o[::2, 1] = np.float32(8.0) + np.abs(o[::2, 1]) % np.float32(40.0)
+    cpu = w.trace_batch(o, d)
+    assert int((cpu["steps"] > 900).sum()) > 100       # walks about as long as a field's range, or beyond it
+    if cells_x >= 2048:
+        assert int(((cpu["steps"] >= 2048) & (cpu["hit"] == 0)).sum()) > 100   # walks that end by MAX_STEPS
+    small = vx.Context(0)
+    small.set_persistent_waves_per_cu(1)
     try:
-        shaded = vx.RenderOptions(shadow=True, bounce_samples=1)
-        for v in (4, 7):
-            ctx.set_kernel_variant(v)
-            assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 5
-            _assert_frame_equal(*_render_both(eng, vxo, w, 160, 96, "A", frame_number=3, shadow=1, bounce_samples=1))
+        _upload(small, w)
+        for c, variant in ((ctx, 4), (small, 4), (ctx, 1)):
+            c.set_kernel_variant(variant)
+            g = c.Raytrace(o, d, want_stats=True)
+            _assert_batch_equal(g, cpu)
+            assert (g["stats"].coarse_probes, g["stats"].brick_entries, g["stats"].fine_probes) == (
+                cpu["stats"].coarse_probes, cpu["stats"].brick_entries, cpu["stats"].fine_probes)
+            _assert_batch_equal(c.Raytrace(o, d), cpu)
+            c.set_kernel_variant(4)
     finally:
-        ctx.set_kernel_variant(default)
+        small.close()
+    shaded = vx.RenderOptions(shadow=True, bounce_samples=1)
+    assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 7 and ctx.kernel_for_launch(160, 96, shaded) == 7
+    _assert_frame_equal(*_render_both(eng, vxo, w, 160, 96, "A", frame_number=3, shadow=1, bounce_samples=1))
+    _assert_frame_equal(*_render_both(eng, vxo, w, 200, 64, "D", frame_number=2, shadow=1, bounce_samples=2, bounce_all_hits=1))
 
 
-def test_kernel_for_launch_reports_the_policy(eng, vxo):
-    """vxrt_kernel_for_launch: what the default (variant 4) resolves to per launch shape, and that a forced variant is
-    reported as itself."""
+def test_kernel_for_launch_reports_the_kernel(eng, vxo):
+    """vxrt_kernel_for_launch: the default runs the persistent kernel (7) for every launch shape -- one view or sixteen, a
+    1080p frame of primary rays or a 1/8 shard -- and the cross-check variant is reported as itself; the kernels of
+    earlier rounds are refused."""
     vx, ctx, torch = eng
-    _upload(ctx, vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32))  # (a world variant 7 fits: 8 x 8 x 8 bricks)
+    _upload(ctx, vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32))
     default = ctx.kernel_variant
     try:
         ctx.set_kernel_variant(4)
         shaded = vx.RenderOptions(shadow=True, bounce_samples=1)
-        # (7 = the persistent kernel on the tracer of vxrt_wave2.hpp; worlds whose coarse grid does not fit its packed step
-        # counters -- more than 1022 x 510 x 1022 cells -- get 5, the same kernel on the round-2 tracer)
-        assert ctx.kernel_for_launch(1920, 1080, shaded, nviews=16) == 7       # several views
-        assert ctx.kernel_for_launch(1920, 1080, shaded) == 7                   # 6.2 M rays
-        assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions()) == 2       # 2.1 M rays, primary only
-        assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions()) == 7       # 8.3 M rays
-        assert ctx.kernel_for_launch(1920, 1080, vx.RenderOptions(shadow=True, checkerboard=True)) == 2  # half the rows
-        assert ctx.kernel_for_launch(3840, 2160, vx.RenderOptions(shadow=True, strip_rows=16, strip_count=8, strip_index=3,
-                                                                  compact=True)) == 2   # a 1/8 shard of a 4K frame
-        for v in (1, 2, 5, 6, 7):
+        for W, H, o, nv in ((1920, 1080, shaded, 16), (1920, 1080, shaded, 0), (1920, 1080, vx.RenderOptions(), 0),
+                            (1280, 720, vx.RenderOptions(mode=1, checkerboard=True), 0), (3840, 2160, vx.RenderOptions(), 0),
+                            (3840, 2160, vx.RenderOptions(shadow=True, strip_rows=16, strip_count=8, strip_index=3, compact=True), 0)):
+            assert ctx.kernel_for_launch(W, H, o, nviews=nv) == 7
+        for v in (1, 7):
             ctx.set_kernel_variant(v)
             assert ctx.kernel_for_launch(640, 480, shaded) == v
-        # the wavefront pipeline keeps one queue per ray generation: beyond 64 generations the fused kernel runs
-        ctx.set_kernel_variant(6)
-        assert ctx.kernel_for_launch(640, 480, vx.RenderOptions(shadow=True, bounce_samples=100)) == 5
-        assert ctx.KERNEL_NAMES[5] == "k_render_persist_lds" and ctx.KERNEL_NAMES[6] == "k_ts_trace" and ctx.KERNEL_NAMES[7] == "k_render_persist2"
-        # variants 0 and 3 are A/B kernels of the experiments build (libvxrt_exp.so): the product library refuses them
-        for v in (0, 3):
-            if ctx.has_experiments():
+        assert ctx.KERNEL_NAMES[7] == "k_render_persist2" and ctx.KERNEL_NAMES[1] == "k_render"
+        for v in (0, 2, 3, 5, 6, 8, -1):
+            with pytest.raises(vx.VxrtError):
                 ctx.set_kernel_variant(v)
-                assert ctx.kernel_for_launch(640, 480, shaded) == v
-            else:
-                with pytest.raises(vx.VxrtError):
-                    ctx.set_kernel_variant(v)
     finally:
         ctx.set_kernel_variant(default)

@@ -1,6 +1,5 @@
-// Debug harness: runs vxrt::trace_wave (one lane) and vxrt::trace_direct on the host against the C oracle.
+// Debug harness: runs vxrt::trace_wave2 (one lane per wave) and vxrt::trace_direct on the host against the C oracle.
 // build: g++ -O1 -g -std=c++17 -ffp-contract=off -Itests/tools/hoststub -Ioracle tests/tools/host_wave_check.cpp oracle/vxo_*.c -lm -lpthread
-#include "../voxelengine_amd/csrc/vxrt_wave.hpp"
 #include "../voxelengine_amd/csrc/vxrt_wave2.hpp"
 extern "C" {
 #include "vxo.h"
@@ -11,14 +10,18 @@ extern "C" {
 using namespace vxrt;
 int main(int argc, char** argv)
 {
+    // usage: host_wave_check f S density n [Sy Sz [wide]]   (S = voxels along x; Sy, Sz default to S; wide = 1 forces the
+    // wide-grid code of vxrt_wave2.hpp on a grid that would not need it)
     int f = argc > 1 ? atoi(argv[1]) : 8, S = argc > 2 ? atoi(argv[2]) : 64;
     double dens = argc > 3 ? atof(argv[3]) : 0.01;
     int n = argc > 4 ? atoi(argv[4]) : 30000;
-    std::vector<uint32_t> dense((size_t)S * S * S / 32, 0);
+    const int Sy = argc > 5 ? atoi(argv[5]) : S, Sz = argc > 6 ? atoi(argv[6]) : S;
+    const int force_wide = argc > 7 ? atoi(argv[7]) : 0;
+    std::vector<uint32_t> dense((size_t)S * Sy * Sz / 32, 0);
     srand(1);
-    for (int z = 0; z < S; ++z) for (int y = 0; y < S; ++y) for (int x = 0; x < S; ++x)
-        if (rand() / (double)RAND_MAX < dens) { uint64_t i = vxo_sample_index64(x, y, z, S, S); dense[i >> 5] |= 1u << (i & 31); }
-    vxo_world* w = vxo_build_brickmap(dense.data(), S, S, S, f);
+    for (int z = 0; z < Sz; ++z) for (int y = 0; y < Sy; ++y) for (int x = 0; x < S; ++x)
+        if (rand() / (double)RAND_MAX < dens) { uint64_t i = vxo_sample_index64(x, y, z, S, Sy); dense[i >> 5] |= 1u << (i & 31); }
+    vxo_world* w = vxo_build_brickmap(dense.data(), S, Sy, Sz, f);
     // the oracle's tables are in the reference's tiled order; the tracer reads the HBM order (linear x, z, y on both
     // levels): re-order on the host what the library re-orders on the device (vxrt_worldgen.hip)
     const int cx = w->cdims[0], cy = w->cdims[1], cz = w->cdims[2];
@@ -49,66 +52,52 @@ int main(int argc, char** argv)
     W.cx = cx; W.cy = cy; W.cz = cz; W.c_row = cx; W.c_slice = cx * cz;
     W.f = f; W.f_row = f; W.f_slice = f * f; W.brick_words = bw; W.ff = (float)f; W.inv_f = 1.0f / f;
     W.wmax_x = (float)((double)W.cx - 1e-6); W.wmax_y = (float)((double)W.cy - 1e-6); W.wmax_z = (float)((double)W.cz - 1e-6);
-    W.X = S; W.Y = S;
-    int bad = 0, bad2 = 0;
+    W.X = S; W.Y = Sy;
+    W.c_wide = (force_wide || grid_is_wide(cx, cy, cz)) ? 1 : 0;
+    const float ext[3] = {(float)S, (float)Sy, (float)Sz};
+    int bad = 0, n_hits = 0, n_long = 0, n_exhausted = 0;  // coverage of the run: hits, walks beyond 1024 steps, rays that ran into MAX_STEPS
     for (int i = 0; i < n; ++i) {
         float o[3], d[3];
-        for (int a = 0; a < 3; ++a) { o[a] = (rand() / (float)RAND_MAX) * (i % 3 ? S : 3 * S) - (i % 3 ? 0 : S); d[a] = rand() / (float)RAND_MAX * 2 - 1; }
+        for (int a = 0; a < 3; ++a) { o[a] = (rand() / (float)RAND_MAX) * (i % 3 ? ext[a] : 3 * ext[a]) - (i % 3 ? 0 : ext[a]); d[a] = rand() / (float)RAND_MAX * 2 - 1; }
         if (i % 7 == 0) d[i % 3] = 0;
         if (i % 11 == 0) { o[0] = floorf(o[0]); o[1] = floorf(o[1]); }
         // adversarial families: tiny / denormal direction components, starts exactly on the far faces (edge rule),
         // far-away origins aimed at the grid, axis-aligned rays along cell boundaries
         if (i % 13 == 0) d[(i / 13) % 3] *= 1e-30f;
         if (i % 17 == 0) d[(i / 17) % 3] = 1e-42f;
-        if (i % 19 == 0) { o[(i / 19) % 3] = (float)S; d[(i / 19) % 3] = -fabsf(d[(i / 19) % 3]) - 0.01f; }
-        if (i % 23 == 0) { for (int a = 0; a < 3; ++a) { o[a] = o[a] * 1000.0f; d[a] = S * 0.5f - o[a]; } }
-        if (i % 31 == 0) { o[0] = o[1] = S * (1.5f + (i % 7)); d[0] = d[1] = -fabsf(d[0]) - 0.1f; }  // exact x/y ties through a grid corner
-        if (i % 37 == 0) { o[1] = o[2] = -S * 0.5f; d[1] = d[2] = fabsf(d[1]) + 0.1f; }
+        if (i % 19 == 0) { o[(i / 19) % 3] = ext[(i / 19) % 3]; d[(i / 19) % 3] = -fabsf(d[(i / 19) % 3]) - 0.01f; }
+        if (i % 23 == 0) { for (int a = 0; a < 3; ++a) { o[a] = o[a] * 1000.0f; d[a] = ext[a] * 0.5f - o[a]; } }
+        if (i % 31 == 0) { o[0] = o[1] = Sy * (1.5f + (i % 7)); d[0] = d[1] = -fabsf(d[0]) - 0.1f; }  // exact x/y ties through a grid corner
+        if (i % 37 == 0) { o[1] = o[2] = -Sy * 0.5f; d[1] = d[2] = fabsf(d[1]) + 0.1f; }
+        // long walks along the long axis (wide grids: the packed counters are re-armed, a walk of MAX_STEPS steps ends the ray)
+        if (i % 5 == 0 && S > 4 * Sy) { d[0] = (i & 8) ? 1.0f : -1.0f; d[1] *= 0.002f; d[2] *= 0.002f; if (i % 10 == 0) o[0] = d[0] > 0 ? -3.0f : S + 3.0f; }
         if (i % 29 == 0) { d[0] = (i & 1) ? 1.0f : -1.0f; d[1] = d[2] = 0; o[1] = floorf(o[1]); o[2] = floorf(o[2]); }
         int steps; float nn[3], pp[3] = {0, 0, 0}; int vox[3] = {0, 0, 0}; vxo_ray_stats st{};
         int h = vxo_raytrace(w, 2048, o, d, &steps, nn, pp, vox, &st);
-        TraceResult t; RayCounters c{0, 0, 0};
-        trace_wave<true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t, c);
-        // the same tracer with its cold state outside the registers (on the GPU: an LDS column per lane) must agree field by field
+        n_hits += h != 0; n_long += steps > 1024; n_exhausted += steps >= 2048 && !h;
+        // the wave-level tracer with one lane per wave, one probe pair between two rounds of votes and three (as
+        // k_render_persist2 runs it): results and the probe counters it derives from its packed step counters
         static uint32_t cold_column[CF_TRACER_FIELDS * 64];
-        TraceResult t2; RayCounters c2{0, 0, 0};
-        trace_wave<true, false, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t2, c2, nullptr, cold_column);
-        bool same2 = t2.hit == t.hit && t2.steps == t.steps && memcmp(&t2.normal, &t.normal, 12) == 0 && c2.coarse_probes == c.coarse_probes &&
-                     c2.brick_entries == c.brick_entries && c2.fine_probes == c.fine_probes;
-        if (t.hit) same2 = same2 && memcmp(&t2.pos, &t.pos, 12) == 0 && t2.vx == t.vx && t2.vy == t.vy && t2.vz == t.vz;
-        // ... and so must a ray that starts from its prepared record (prepare_ray + begin_prepared: the traversal kernel's start)
-        TraceResult t3; RayCounters c3{0, 0, 0};
-        trace_wave<true, false, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t3, c3, nullptr, cold_column, true);
-        same2 = same2 && t3.hit == t.hit && t3.steps == t.steps && memcmp(&t3.normal, &t.normal, 12) == 0 && c3.coarse_probes == c.coarse_probes &&
-                c3.brick_entries == c.brick_entries && c3.fine_probes == c.fine_probes;
-        if (t.hit) same2 = same2 && memcmp(&t3.pos, &t.pos, 12) == 0 && t3.vx == t.vx && t3.vy == t.vy && t3.vz == t.vz;
-        // the tracer built for the vector pipe's two instruction classes (vxrt_wave2.hpp): same results
-        if (tracer2_fits(W)) {
-            TraceResult t4{};
-            RayCounters c4{0, 0, 0}, c5{0, 0, 0};
-            trace_wave2<1, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
-            // ... and with three probe pairs between two rounds of votes, as k_render_persist2 runs it
-            TraceResult t5{};
-            trace_wave2<3, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
-            bool s4 = t4.hit == t.hit && t4.steps == t.steps && t5.hit == t.hit && t5.steps == t.steps;
-            // the probe counters this tracer derives from its packed step counters at the end of each walk: the oracle's
-            s4 = s4 && c4.coarse_probes == st.coarse_probes && c4.brick_entries == st.brick_entries && c4.fine_probes == st.fine_probes;
-            s4 = s4 && c5.coarse_probes == st.coarse_probes && c5.brick_entries == st.brick_entries && c5.fine_probes == st.fine_probes;
-            if (t.hit) s4 = s4 && memcmp(&t5.pos, &t.pos, 12) == 0 && memcmp(&t5.normal, &t.normal, 12) == 0 && t5.vx == t.vx && t5.vy == t.vy && t5.vz == t.vz;
-            if (t.hit) s4 = s4 && memcmp(&t4.pos, &t.pos, 12) == 0 && memcmp(&t4.normal, &t.normal, 12) == 0 && t4.vx == t.vx && t4.vy == t.vy && t4.vz == t.vz;
-            if (!s4 && bad2++ < 5)
-                printf("tracer2: ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g): hit %d/%d steps %d/%d pos (%.9g,%.9g,%.9g)/(%.9g,%.9g,%.9g) vox (%d,%d,%d)/(%d,%d,%d) probes %u/%u/%u vs %llu/%llu/%llu\n", i, o[0], o[1], o[2], d[0], d[1], d[2],
-                       t4.hit, t.hit, t4.steps, t.steps, t4.pos.x, t4.pos.y, t4.pos.z, t.pos.x, t.pos.y, t.pos.z, t4.vx, t4.vy, t4.vz, t.vx, t.vy, t.vz,
-                       c4.coarse_probes, c4.brick_entries, c4.fine_probes, (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries, (unsigned long long)st.fine_probes);
-            same2 = same2 && s4;
-        }
-        bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries && c.fine_probes == st.fine_probes;
-        if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
-        ok = ok && same2;
+        TraceResult t4{}, t5{};
+        RayCounters c4{0, 0, 0}, c5{0, 0, 0};
+        trace_wave2<1, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
+        trace_wave2<3, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
+        // ... and the straightforward loops the cross-check kernels run
+        TraceResult t1{}; RayCounters c1{0, 0, 0};
+        trace_direct(W, 2048, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t1, c1);
+        auto same = [&](const TraceResult& t, const RayCounters& c) {
+            bool ok = (t.hit == (h != 0)) && t.steps == steps && c.coarse_probes == st.coarse_probes && c.brick_entries == st.brick_entries &&
+                      c.fine_probes == st.fine_probes;
+            if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
+            return ok;
+        };
+        const bool ok = same(t4, c4) && same(t5, c5) && same(t1, c1);
         if (!ok && bad++ < 5)
-            printf("ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g) cpu hit=%d steps=%d probes=%llu/%llu/%llu | wave hit=%d steps=%d probes=%u/%u/%u\n", i, o[0], o[1], o[2], d[0], d[1], d[2], h, steps,
-                   (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries, (unsigned long long)st.fine_probes, t.hit, t.steps, c.coarse_probes, c.brick_entries, c.fine_probes);
+            printf("ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g) oracle hit=%d steps=%d probes=%llu/%llu/%llu pos (%.9g,%.9g,%.9g) vox (%d,%d,%d) | wave2 hit=%d steps=%d probes=%u/%u/%u pos (%.9g,%.9g,%.9g) vox (%d,%d,%d) | x3 %d | direct %d\n",
+                   i, o[0], o[1], o[2], d[0], d[1], d[2], h, steps, (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries,
+                   (unsigned long long)st.fine_probes, pp[0], pp[1], pp[2], vox[0], vox[1], vox[2], t4.hit, t4.steps, c4.coarse_probes, c4.brick_entries,
+                   c4.fine_probes, t4.pos.x, t4.pos.y, t4.pos.z, t4.vx, t4.vy, t4.vz, (int)same(t5, c5), (int)same(t1, c1));
     }
-    printf("mismatches %d of %d\n", bad, n);
+    printf("mismatches %d of %d  (hits %d, rays of more than 1024 steps %d, of 2048 or more without a hit %d)\n", bad, n, n_hits, n_long, n_exhausted);
     return bad != 0;
 }

@@ -1,4 +1,4 @@
-// Host stand-in for the few HIP device builtins vxrt_device.hpp / vxrt_wave.hpp use, so the traversal code can be
+// Host stand-in for the few HIP device builtins vxrt_device.hpp / vxrt_wave2.hpp use, so the traversal code can be
 // compiled for the CPU with ONE lane per "wave" and stepped in a debugger / compared with the oracle.
 // Debug tooling only (tests/tools/host_wave_check.cpp); never part of the product build.
 #pragma once

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/ab_configs.sh <out-tag> <variant> ...   (on the GPU box via gpurun)
 # the BASELINE configurations other than bench.py's default, each with the given render kernel variants
-# (bench.py --kernel-variant: 4 = the library's policy, 2, 5, 6, 1)
+# (bench.py --kernel-variant: 4 = the product kernel, 1 = the straightforward loops)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/abc_$1; shift

@@ -11,6 +11,10 @@ run() {
   [[ "$1" == *:* ]] && wpc=${1##*:}
   local lib=$R/voxelengine_amd/csrc/libvxrt.so
   [ "$tag" != base ] && lib=$R/voxelengine_amd/csrc/libvxrt_$tag.so
+  # an A/B library must come from the sources the product library was built from (tools/build_variant.sh stamps it)
+  if [ "$tag" != base ] && [ "$(head -1 $lib.srchash 2>/dev/null)" != "$(head -1 $R/voxelengine_amd/csrc/libvxrt.so.srchash)" ]; then
+    echo "$lib is stale (or was not built by tools/build_variant.sh): rebuild it"; exit 1
+  fi
   VXRT_LIB=$lib VXRT_WAVES_PER_CU=$wpc VXRT_SKIP_STALE_CHECK=1 python3 $R/bench.py --cpu-baseline off ${BENCH_ARGS:-} > $OUT/$2.json 2> $OUT/$2.err || { echo "$1 failed"; tail -20 $OUT/$2.err; echo "stopping: no further GPU run behind a failed one (full log: $OUT/$2.err)"; exit 1; }
   python3 - "$OUT/$2.json" "$1" <<'PY'
 import json, sys

@@ -1,4 +1,4 @@
-"""Diagnostics of the persistent render kernel (variant 2) on a bench workload: lane utilisation of the loop, average
+"""Diagnostics of the persistent render kernel (k_render_persist2) on a bench workload: lane utilisation of the loop, average
 wave lifetime against the launch duration (tail / imbalance) and the share of iterations run after the tile queue ran
 dry.  Uses the probe-counting launch (collect_stats), which is slower than the timed kernel but has the same shape.
 

@@ -17,7 +17,7 @@
 #include <vector>
 
 namespace vxrt {
-hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream, const TsArgs* ts);
+hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream);
 int resolve_render_variant(const RenderArgs& A, int variant);
 hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipStream_t stream);
 void launch_deinterleave(const void* shards, unsigned long long shard_stride_bytes, void* fb, uint32_t width,
@@ -64,8 +64,7 @@ struct vxrt_ctx {
     float fov = 90.0f;               // hFrameInfo initial value, Renderer.cu:25
     float ortho[2] = {10.0f, 10.0f};
     uint32_t frame_counter = 0;
-    int kernel_variant = 4;          // render: 4 = persistent waves, kernel picked per launch (resolve_render_variant); 2 / 3 / 5 = one of
-                                     // the two persistent kernels everywhere; 0 = wave state machine, 1 = straightforward
+    int kernel_variant = 4;          // 4 = default (= 7: the persistent kernels on the tracer of vxrt_wave2.hpp), 1 = straightforward loops
     unsigned persistent_waves = 4096;
     unsigned cus = 256;
     unsigned long long* d_stats = nullptr;
@@ -80,15 +79,6 @@ struct vxrt_ctx {
     vxrt::ViewArgs* d_views = nullptr;
     std::atomic<unsigned> view_seq{0};
     hipEvent_t views_busy[16] = {};
-    // Workspaces of the traversal/shading pipeline (variant 6, vxrt_ts.hpp): ray queues, results and pixel chain state in HBM.
-    // A ring, like the queue heads: a launch takes the next entry, grows it if its frame needs more, and waits for the launch
-    // that used it last if that one is still in flight (so two frames in flight on two streams never share queues).
-    struct TsSlot {
-        void* mem = nullptr;
-        size_t bytes = 0;
-        hipEvent_t busy = nullptr;
-    } ts_ring[3];
-    std::atomic<unsigned> ts_seq{0};
     int batch_max_steps = vxrt::kMaxSteps;  // Raytrace's maxSteps for the batch API (vxrt_set_batch_max_steps)
     struct StreamState* stream = nullptr;   // chunk streaming (vxrt_stream_*), or NULL
 };
@@ -123,9 +113,11 @@ int check_shape(int factor, const int cd[3])
     for (int a = 0; a < 3; ++a)
         if (cd[a] <= 0 || cd[a] % 8 != 0 || cd[a] > 65535)
             return fail(VXRT_ERR_INVALID, "coarse dimensions must be positive multiples of 8 (the tables' tiled order)");
-    // cell_index(): 24-bit multiply-adds on the strides cx and cx * cz, 32-bit cell indices
-    if ((uint64_t)cd[0] * (uint64_t)cd[2] >= (1ull << 24) || (uint64_t)cd[0] * cd[1] * cd[2] >= (1ull << 32))
-        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit cell indices (cx * cz must stay below 2^24)");
+    // cell_index(): x + cx * (z + cz * y) by two 24-bit multiply-adds, 32-bit bit indices biased by one x-z slice, and a
+    // lane that has just left the grid may look one more slice ahead (vxrt_wave2.hpp)
+    const uint64_t slice = (uint64_t)cd[0] * (uint64_t)cd[2];
+    if ((uint64_t)cd[1] * (uint64_t)cd[2] >= (1ull << 24) || slice * (uint64_t)cd[1] + 2ull * slice + 64ull >= (1ull << 32))
+        return fail(VXRT_ERR_INVALID, "coarse grid too large for 32-bit cell indices (cy * cz must stay below 2^24, cx * cz * (cy + 2) below 2^32)");
     return VXRT_OK;
 }
 
@@ -151,6 +143,7 @@ void fill_view(vxrt_ctx* c, int factor, const int cd[3])
     v.wmax_z = (float)((double)cd[2] - 1e-6);
     v.X = cd[0] * factor;
     v.Y = cd[1] * factor;
+    v.c_wide = grid_is_wide(cd[0], cd[1], cd[2]) ? 1 : 0;
 }
 
 int alloc_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t pool_slots)
@@ -221,52 +214,6 @@ static hipError_t ring_release(hipEvent_t& ev, hipStream_t stream, bool capturin
     return hipEventRecord(ev, stream);
 }
 
-// Lease a traversal/shading workspace for one launch of `A` (variant 6): carve the ring entry into the pipeline's arrays.
-static int ts_lease(vxrt_ctx* c, const RenderArgs& A, hipStream_t stream, TsArgs& S, unsigned& slot_index, bool& capturing)
-{
-    const unsigned long long nv = A.nviews ? A.nviews : 1u;
-    const unsigned long long tiles = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u);
-    const unsigned long long slots = tiles * 64ull * nv;          // queue capacity: no generation has more rays than pixels
-    auto up = [](unsigned long long b) { return (b + 255ull) & ~255ull; };
-    const unsigned long long groups = tiles * nv;
-    const unsigned long long b_rays = up(slots * 64ull), b_idx = up(slots), b_gcnt = up(groups * 4ull), b_res = up(slots * 16ull),
-                             b_vox = A.want_hit_aov ? up(slots * 8ull) : 0ull, b_state = up(slots * 32ull),
-                             b_tick = up((unsigned long long)(kTsMaxGenerations + 1u) * kTsShards * 64u * sizeof(unsigned int));
-    const unsigned long long need = 2 * b_rays + 2 * b_idx + 2 * b_gcnt + b_res + b_vox + b_state + b_tick;
-    slot_index = c->ts_seq.fetch_add(1u) % 3u;
-    vxrt_ctx::TsSlot& T = c->ts_ring[slot_index];
-    hipError_t e = ring_acquire(T.busy, stream, capturing);
-    if (e != hipSuccess)
-        return fail(VXRT_ERR_HIP, std::string("workspace ring: ") + hipGetErrorString(e));
-    if (T.bytes < need) {
-        if (capturing)
-            return fail(VXRT_ERR_INVALID, "the traversal/shading workspace must be sized before stream capture: render the frame once first");
-        if (T.mem)
-            (void)hipFree(T.mem);  // (the entry's last launch has finished: ring_acquire waited for it)
-        T.mem = nullptr;
-        T.bytes = 0;
-        e = hipMalloc(&T.mem, need);
-        if (e != hipSuccess)
-            return fail(VXRT_ERR_NOMEM, std::string("traversal/shading workspace: ") + hipGetErrorString(e));
-        T.bytes = need;
-    }
-    unsigned char* at = static_cast<unsigned char*>(T.mem);
-    auto take = [&](unsigned long long b) { unsigned char* r = at; at += b; return r; };
-    S.rays[0] = reinterpret_cast<uint4*>(take(b_rays));
-    S.rays[1] = reinterpret_cast<uint4*>(take(b_rays));
-    S.idx[0] = reinterpret_cast<uint8_t*>(take(b_idx));
-    S.idx[1] = reinterpret_cast<uint8_t*>(take(b_idx));
-    S.gcount[0] = reinterpret_cast<uint32_t*>(take(b_gcnt));
-    S.gcount[1] = reinterpret_cast<uint32_t*>(take(b_gcnt));
-    S.res = reinterpret_cast<uint4*>(take(b_res));
-    S.res_voxel = b_vox ? reinterpret_cast<long long*>(take(b_vox)) : nullptr;
-    S.pstate = reinterpret_cast<uint4*>(take(b_state));
-    S.tickets = reinterpret_cast<unsigned int*>(take(b_tick));
-    S.slots_per_view = (uint32_t)(tiles * 64ull);
-    S.groups = (uint32_t)groups;
-    return VXRT_OK;
-}
-
 // Default hand-out order of the persistent kernel's tile queue: expected-longest ray chains first, so that what is
 // still in flight when the queue runs dry is cheap.  The cost proxy needs the camera only: the elevation of the
 // centre ray of each 8-pixel tile row in a Y-up world -- rays just below the horizon travel farthest, rays
@@ -280,7 +227,7 @@ static void schedule_tile_rows(const RenderArgs& A, const f3& fwd, const f3& up,
     std::vector<std::pair<float, uint16_t>> key(nty);
     for (unsigned j = 0; j < nty; ++j) {
         unsigned row = j * 8u + 4u < A.launch_rows ? j * 8u + 4u : A.launch_rows - 1u;
-        unsigned y = row;  // launch row -> frame row (pixel_coords in vxrt_persist.hpp)
+        unsigned y = row;  // launch row -> frame row (pixel_coords in vxrt_persist2.hpp)
         if (A.checkerboard)
             y = 2u * row;
         else if (A.strip_count > 1)
@@ -336,10 +283,7 @@ int vxrt_create(int device, vxrt_ctx** out)
         c->persistent_waves = (unsigned)prop.multiProcessorCount * 16u;  // 4 waves per SIMD at <= 128 VGPRs
         c->cus = (unsigned)prop.multiProcessorCount;
 #ifdef VXRT_EXPERIMENTS  // A/B builds only (make libvxrt_exp.so): the product library reads no environment variable
-        if (const char* v = getenv("VXRT_VARIANT"))                       // A/B of the render kernels (tools/)
-            if (atoi(v) >= 0 && atoi(v) <= 6)
-                c->kernel_variant = atoi(v);
-        if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy experiments
+        if (const char* e = getenv("VXRT_WAVES_PER_CU"))                  // occupancy / grid experiments
             if (atoi(e) > 0 && atoi(e) <= 32)
                 c->persistent_waves = (unsigned)prop.multiProcessorCount * (unsigned)atoi(e);
 #endif
@@ -361,10 +305,6 @@ int vxrt_destroy(vxrt_ctx* c)
     vxrt::free_world(c);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_views) (void)hipFree(c->d_views);
-    for (auto& t : c->ts_ring) {
-        if (t.mem) (void)hipFree(t.mem);
-        if (t.busy) (void)hipEventDestroy(t.busy);
-    }
     for (hipEvent_t& e : c->counter_busy)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t& e : c->views_busy)
@@ -380,7 +320,7 @@ int vxrt_kernel_for_launch(const vxrt_ctx* c, uint32_t width, uint32_t height, c
     vxrt::RenderArgs A;
     memset(&A, 0, sizeof(A));
     if (c->has_world)
-        A.W = c->view;  // (variant 7 depends on the resident world's dimensions: vxrt_wave2.hpp, tracer2_fits)
+        A.W = c->view;
     A.width = width;
     A.shadow = fl->shadow ? 1 : 0;
     A.bounce_samples = fl->bounce_samples;
@@ -414,12 +354,8 @@ int vxrt_has_experiments(void)
 
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
 {
-#ifndef VXRT_EXPERIMENTS
-    if (c && (variant == 0 || variant == 3))
-        return fail(VXRT_ERR_INVALID, "render kernel variants 0 (wave state machine) and 3 (LDS pixel pool) are A/B kernels of the experiments build (make -C voxelengine_amd/csrc libvxrt_exp.so)");
-#endif
-    if (!c || variant < 0 || variant > 7)
-        return fail(VXRT_ERR_INVALID, "variant must be 0 (wave), 1 (direct), 2 (persistent), 3 (persistent, pixel pool in LDS), 4 (default, picked per launch), 5 (persistent, cold state in LDS, 5 waves per SIMD), 6 (traversal / shading kernels over ray queues) or 7 (variant 5 on the tracer of vxrt_wave2.hpp)");
+    if (!c || !(variant == 1 || variant == 4 || variant == 7))
+        return fail(VXRT_ERR_INVALID, "variant must be 4 (default), 7 (the persistent kernels on the wave-level tracer: what the default runs) or 1 (straightforward per-lane loops, the cross-check)");
     c->kernel_variant = variant;
     return VXRT_OK;
 }
@@ -742,7 +678,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
         A.launch_rows = height;
     A.stats = c->d_stats;  // counters accumulate until vxrt_frame_stats_get reads and clears them
     A.persistent_waves = c->persistent_waves;
-    const bool persistent = c->kernel_variant >= 2;
+    const bool persistent = c->kernel_variant != 1;
     const bool schedule = fl->tile_schedule && persistent;
 
     auto frame_number_of = [&](const vxrt_view& v) -> uint32_t {
@@ -752,7 +688,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     };
     auto f3_of = [](const float* p) { return vxrt::f3{p[0], p[1], p[2]}; };
 
-    if (nviews == 0 || !persistent) {  // single-view kernel arguments; variants 0/1 take the views one by one
+    if (nviews == 0 || !persistent) {  // single-view kernel arguments; variant 1 takes the views one by one
         for (unsigned v = 0; v < n; ++v) {
             A.frame_number = frame_number_of(views[v]);
             A.origin = f3_of(views[v].origin);
@@ -771,19 +707,8 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
             bool capturing = false;
             VX_HIP(vxrt::ring_acquire(c->counter_busy[slot], stream, capturing));
             A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + slot;
-            vxrt::TsArgs ts;
-            unsigned ts_slot = 0;
-            bool ts_cap = false;
-            const bool use_ts = vxrt::resolve_render_variant(A, c->kernel_variant) == 6;
-            if (use_ts) {
-                const int rc = vxrt::ts_lease(c, A, stream, ts, ts_slot, ts_cap);
-                if (rc)
-                    return rc;
-            }
-            VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream, use_ts ? &ts : nullptr));
+            VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
             VX_HIP(hipGetLastError());
-            if (use_ts)
-                VX_HIP(vxrt::ring_release(c->ts_ring[ts_slot].busy, stream, ts_cap));
             VX_HIP(vxrt::ring_release(c->counter_busy[slot], stream, capturing));
         }
         return VXRT_OK;
@@ -817,19 +742,8 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     A.views = slot;
     A.nviews = n;
     A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + cslot;
-    vxrt::TsArgs ts;
-    unsigned ts_slot = 0;
-    bool ts_cap = false;
-    const bool use_ts = vxrt::resolve_render_variant(A, c->kernel_variant) == 6;
-    if (use_ts) {
-        const int rc = vxrt::ts_lease(c, A, stream, ts, ts_slot, ts_cap);
-        if (rc)
-            return rc;
-    }
-    VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream, use_ts ? &ts : nullptr));
+    VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
     VX_HIP(hipGetLastError());
-    if (use_ts)
-        VX_HIP(vxrt::ring_release(c->ts_ring[ts_slot].busy, stream, ts_cap));
     VX_HIP(vxrt::ring_release(c->views_busy[vslot], stream, capturing));
     VX_HIP(vxrt::ring_release(c->counter_busy[cslot], stream, capturing));
     return VXRT_OK;
@@ -873,7 +787,7 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     VX_HIP(hipDeviceSynchronize());  // every stream of the device, non-blocking ones included
     unsigned long long now[vxrt::kStatCount], h[vxrt::kStatCount];
     VX_HIP(hipMemcpy(now, c->d_stats, sizeof(now), hipMemcpyDeviceToHost));
-    for (int i = 0; i < vxrt::kStatBrickHist; ++i) {  // what was added since the previous read; the device copy only grows
+    for (int i = 0; i < vxrt::kStatCount; ++i) {  // what was added since the previous read; the device copy only grows
         h[i] = now[i] - c->stats_base[i];
         c->stats_base[i] = now[i];
     }
@@ -896,22 +810,6 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     out->dbg[9] = h[vxrt::kStatDbgDrained];
     out->dbg[10] = h[vxrt::kStatDbgNextTicks];
     out->dbg[11] = h[vxrt::kStatDbgParkTicks];
-    return VXRT_OK;
-}
-
-int vxrt_debug_brick_histogram(vxrt_ctx* c, uint64_t out[130])
-{
-    static_assert(vxrt::kStatBrickHistFineOnly == vxrt::kStatBrickHist + 65 && vxrt::kStatCount == vxrt::kStatBrickHist + 130, "histogram layout");
-    if (!c || !out)
-        return fail(VXRT_ERR_INVALID, "NULL argument");
-    VX_HIP(hipSetDevice(c->device));
-    VX_HIP(hipDeviceSynchronize());
-    unsigned long long now[130];
-    VX_HIP(hipMemcpy(now, c->d_stats + vxrt::kStatBrickHist, sizeof(now), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 130; ++i) {  // since the previous read, like vxrt_frame_stats_get
-        out[i] = now[i] - c->stats_base[vxrt::kStatBrickHist + i];
-        c->stats_base[vxrt::kStatBrickHist + i] = now[i];
-    }
     return VXRT_OK;
 }
 
@@ -975,17 +873,6 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     B.ticket = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + tslot;
     B.persistent_waves = c->persistent_waves;
     B.max_steps = c->batch_max_steps;
-    unsigned int* d_dbg = nullptr;
-#ifdef VXRT_EXPERIMENTS
-    const bool debug_trace = getenv("VXRT_DEBUG_TRACE") != nullptr;
-#else
-    const bool debug_trace = false;
-#endif
-    if (stats && debug_trace) {  // development: dump the wave loop's view of ray 0
-        VX_HIP(hipMalloc((void**)&d_dbg, 400 * 12 * 4));
-        VX_HIP(hipMemset(d_dbg, 0xFF, 400 * 12 * 4));
-        B.dbg_trace = d_dbg;
-    }
     if (stats) {  // a stats request reports what ran between two device-wide syncs: this batch alone if nothing else is submitted
         vxrt_frame_stats drop;
         int rc = vxrt_frame_stats_get(c, &drop);
@@ -997,19 +884,6 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     VX_HIP(vxrt::ring_release(c->counter_busy[tslot], stream, capturing));
     if (stats) {
         VX_HIP(hipStreamSynchronize(stream));
-        if (d_dbg) {
-            std::vector<unsigned int> h(400 * 12);
-            VX_HIP(hipMemcpy(h.data(), d_dbg, h.size() * 4, hipMemcpyDeviceToHost));
-            (void)hipFree(d_dbg);
-            for (int it = 0; it < 400 && h[it * 12] != 0xFFFFFFFFu; ++it) {
-                const unsigned int* r = &h[it * 12];
-                float tn[3], ws[2];
-                memcpy(tn, r + 5, 12);
-                memcpy(ws, r + 10, 8);
-                fprintf(stderr, "it %d st=%u fine=%u cell=(%d,%d,%d) tn=(%.9g,%.9g,%.9g) steps=%d total=%d ws=(%.9g,%.9g)\n", it, r[0], r[1],
-                        (int)r[2], (int)r[3], (int)r[4], tn[0], tn[1], tn[2], (int)r[8], (int)r[9], ws[0], ws[1]);
-            }
-        }
         return vxrt_frame_stats_get(c, stats);
     }
     return VXRT_OK;

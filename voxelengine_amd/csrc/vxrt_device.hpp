@@ -47,7 +47,7 @@ struct WorldView {
     const uint2* __restrict__ cell_meta;
     const uint32_t* __restrict__ pool;
     int cx, cy, cz;        // coarse cells per axis
-    int c_row, c_slice;    // coarse cells per x-row (cx), per x-z plane (cx * cz): the strides of cell_index()
+    int c_row, c_slice;    // coarse cells per x-row (cx), per x-z plane (cx * cz): what a step along z / y adds to a bit index
     int f;                 // brick edge (8, 16, 32)
     int f_row, f_slice;    // brick voxels per x-row (f), per x-z plane (f * f)
     uint32_t brick_words;  // f^3 / 32
@@ -55,12 +55,27 @@ struct WorldView {
     float inv_f;           // 1/f, exact because f is a power of two: x / f == x * inv_f bit for bit
     float wmax_x, wmax_y, wmax_z;  // (float)((double)c - 1e-6), VolumeRaytracer.cu:375-376
     int X, Y;              // world voxels per axis (hit voxel index)
+    int c_wide;            // the coarse grid exceeds WaveTracer2's packed step counters (vxrt_wave2.hpp, "wide grids"): set by the host
 };
+
+// WaveTracer2 (vxrt_wave2.hpp) packs the steps left to the coarse grid's faces into 11 + 10 + 11 bits; a grid beyond that,
+// or one a single walk could cross in MAX_STEPS iterations or more, is "wide" (WorldView::c_wide): the fields then count
+// down to virtual faces and are re-armed on the way.
+// largest value a field of rem is armed with on a wide grid: the history (rp, rpp) adds up to two steps back, below the guards
+#ifndef VXRT_FIELD_CAP_XZ  // (the host harness re-arms every few steps with small caps)
+#define VXRT_FIELD_CAP_XZ 1020u
+#define VXRT_FIELD_CAP_Y 508u
+#endif
+constexpr uint32_t kFieldCapXZ = VXRT_FIELD_CAP_XZ, kFieldCapY = VXRT_FIELD_CAP_Y;
+
+__host__ __device__ inline bool grid_is_wide(int cx, int cy, int cz)
+{
+    return cx > (int)kFieldCapXZ || cz > (int)kFieldCapXZ || cy > (int)kFieldCapY || cx + cy + cz + 4 >= kMaxSteps;
+}
+
 
 struct RayCounters {
     uint32_t coarse_probes, brick_entries, fine_probes;
-    // loop diagnostics of the wave tracer (probe-counting kernel variant only; wave-uniform values)
-    uint32_t iters = 0, walk_lanes = 0, end_runs = 0, box_runs = 0;
 };
 
 // float -> int as the hardware does it (v_cvt_i32_f32): truncation, saturating, NaN -> 0.  Spelled with the
@@ -114,15 +129,16 @@ __device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b, uint32_t c)
 }
 #endif
 
-// HBM order: x fastest, then z, then y -- bit x + row * z + slice * y, row = cells along x, slice = cells in an x-z
-// plane.  y last because it is the world's short, vertical axis: rays move mostly in x and z, so consecutive probes of
-// a ray stay in one word (x steps) or one 64-byte line (z steps) more often than with y in the middle.
-__device__ __forceinline__ uint32_t cell_index(int x, int y, int z, int row, int slice)
+// HBM order: x fastest, then z, then y -- bit x + row * (z + dz * y), row = cells along x, dz = cells along z.  y last
+// because it is the world's short, vertical axis: rays move mostly in x and z, so consecutive probes of a ray stay in one
+// word (x steps) or one 64-byte line (z steps) more often than with y in the middle.
+__device__ __forceinline__ uint32_t cell_index(int x, int y, int z, int row, int dz)
 {
-    // 24-bit multiply-adds (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate): coordinates < 2^16, strides < 2^24
-    // (checked when a world is uploaded or built).  Spelled as the instruction: given __umul24 the compiler still
-    // selects the 32-bit multiply when it cannot prove the operands' width.
-    return mad24((uint32_t)y, (uint32_t)slice, mad24((uint32_t)z, (uint32_t)row, (uint32_t)x));
+    // 24-bit multiply-adds (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate): coordinates < 2^16 and dy * dz < 2^24
+    // (checked when a world is uploaded or built), so the inner sum stays below 2^24 whatever the grid's x-z plane holds --
+    // 4096 x 16 x 4096 bricks, the reference's stated goal (VoxelApp/main.cu:20), included.  Spelled as the instruction:
+    // given __umul24 the compiler still selects the 32-bit multiply when it cannot prove the operands' width.
+    return mad24(mad24((uint32_t)y, (uint32_t)dz, (uint32_t)z), (uint32_t)row, (uint32_t)x);
 }
 // the same order for the cold code (re-ordering kernels, builders, host): index of a cell of a dx x dy x dz grid, and back
 __host__ __device__ inline uint64_t hbm_index(int x, int y, int z, int dx, int dz)
@@ -222,7 +238,7 @@ struct WalkResult {
 // point applies (:325-341).
 template <bool COARSE>
 __device__ void walk_level(const WorldView& W, const uint32_t* __restrict__ bits, int dim_x, int dim_y, int dim_z,
-                           int row, int slice, f3 s, f3 d, WalkResult& R, uint32_t& probes)
+                           f3 s, f3 d, WalkResult& R, uint32_t& probes)
 {
     int cell_x = f2i(s.x), cell_y = f2i(s.y), cell_z = f2i(s.z);
     const int sgn_x = d.x > 0 ? 1 : -1, sgn_y = d.y > 0 ? 1 : -1, sgn_z = d.z > 0 ? 1 : -1;
@@ -259,7 +275,7 @@ __device__ void walk_level(const WorldView& W, const uint32_t* __restrict__ bits
             R.hy = qy;
             R.hz = qz;
             probes += 1;
-            uint32_t idx = cell_index(qx, qy, qz, row, slice);
+            uint32_t idx = cell_index(qx, qy, qz, dim_x, dim_z);
             bool solid = bits ? ((bits[idx >> 5] >> (idx & 31u)) & 1u) != 0u : false;
             if (COARSE) {
                 if (solid) {
@@ -334,7 +350,7 @@ struct TraceResult {
     f3 pos;     // valid on hit
     f3 normal;  // step-direction convention; zero on a miss
     int vx, vy, vz;  // global voxel that ended the ray (valid on hit)
-    uint32_t ncode;  // wave tracer only: `normal` as its small code (normal_decode, vxrt_wave.hpp)
+    uint32_t ncode;  // wave tracer only: `normal` as its small code (normal_decode, vxrt_wave2.hpp)
 };
 
 // Raytrace (VolumeRaytracer.cu:354-525), straightforward form.
@@ -361,7 +377,7 @@ __device__ void trace_direct(const WorldView& W, int max_steps, f3 origin, f3 ra
 
     while (total < max_steps) {
         WalkResult c;
-        walk_level<true>(W, W.coarse_bits, W.cx, W.cy, W.cz, W.c_row, W.c_slice, start, dir, c, cnt.coarse_probes);
+        walk_level<true>(W, W.coarse_bits, W.cx, W.cy, W.cz, start, dir, c, cnt.coarse_probes);
         total += c.steps;
         f3 local = mk3(c.point.x * W.ff, c.point.y * W.ff, c.point.z * W.ff);
         hit_pos = local;
@@ -375,7 +391,7 @@ __device__ void trace_direct(const WorldView& W, int max_steps, f3 origin, f3 ra
         last_z = hz;
         local = mk3(local.x - hx * W.ff, local.y - hy * W.ff, local.z - hz * W.ff);
 
-        uint32_t ci = cell_index(c.hx, c.hy, c.hz, W.c_row, W.c_slice);
+        uint32_t ci = cell_index(c.hx, c.hy, c.hz, W.cx, W.cz);
         uint32_t slot = W.cell_meta[ci].x;
         const uint32_t* bits = nullptr;
         int bd = 0;
@@ -385,7 +401,7 @@ __device__ void trace_direct(const WorldView& W, int max_steps, f3 origin, f3 ra
         }
         cnt.brick_entries += 1;
         WalkResult b;
-        walk_level<false>(W, bits, bd, bd, bd, W.f_row, W.f_slice, local, dir, b, cnt.fine_probes);
+        walk_level<false>(W, bits, bd, bd, bd, local, dir, b, cnt.fine_probes);
         total += b.steps;
         hit_pos = mk3(b.point.x + hx * W.ff, b.point.y + hy * W.ff, b.point.z + hz * W.ff);
         if (b.hit) {

@@ -1,8 +1,11 @@
 // vxrt_kernels.hip -- gfx950 kernels: per-pixel render (screenDispatch, VoxelRT/Renderer.cu:179-276),
 // batch trace (dispatch, VoxelRT/VolumeRaytracer.cu:95-117) and the strip de-interleave used after the
-// multi-GPU gather.  One wavefront (64 lanes) owns an 8x8 pixel tile; a 256-thread workgroup owns 16x16.
+// multi-GPU gather, with their launchers.  The product kernels are k_render_persist2 (vxrt_persist2.hpp),
+// k_trace_batch_persist (vxrt_batch_persist.hpp) and k_trace_batch_wave2 below, all on the tracer of vxrt_wave2.hpp;
+// k_render and k_trace_batch are the straightforward per-lane loops of vxrt_device.hpp, kept as the cross-check
+// (kernel variant 1).
 #include "vxrt_kernels.hpp"
-#include "vxrt_wave.hpp"
+#include "vxrt_wave2.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -332,253 +335,14 @@ __global__ __launch_bounds__(256) void k_deinterleave(const uint4* __restrict__ 
 // ---- wave-level kernels (vxrt_wave.hpp): every trace is entered by the whole wavefront at a converged point
 // with an `active` predicate, so the ballots inside see all 64 lanes ---------------------------------------
 
-#ifdef VXRT_EXPERIMENTS  // variant 0: A/B builds only (make libvxrt_exp.so)
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_render_wave(RenderArgs A)
-{
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t tile = blockDim.x == 64u ? 8u : 16u;  // one 8x8 wave tile per workgroup, or 2x2 of them
-    const uint32_t tx = blockIdx.x * tile + (wave & 1) * 8 + (lane & 7);
-    const uint32_t row = blockIdx.y * tile + (wave >> 1) * 8 + (lane >> 3);
-
-    RayCounters cnt = {0, 0, 0};
-    uint32_t n_primary = 0, n_shadow = 0, n_bounce = 0, n_hits = 0;
-
-    uint32_t ty = row;
-    const bool sharded = A.strip_count > 1;
-    if (sharded && !A.checkerboard) {
-        uint32_t strip = (row / (uint32_t)A.strip_rows) * (uint32_t)A.strip_count + (uint32_t)A.strip_index;
-        ty = strip * (uint32_t)A.strip_rows + row % (uint32_t)A.strip_rows;
-    }
-    bool live = row < A.launch_rows;
-    int x = (int)tx, y = (int)ty;
-    if (A.checkerboard) {  // Renderer.cu:186-194
-        y *= 2;
-        if ((x % 2) == 0)
-            y += 1;
-        if (A.frame_number % 2 == 0)
-            y += 1;
-    }
-    live = live && (uint32_t)x < A.width && (uint32_t)y < A.height;
-    if (live && sharded && ((uint32_t)y / (uint32_t)A.strip_rows) % (uint32_t)A.strip_count != (uint32_t)A.strip_index)
-        live = false;
-
-    const int Wd = (int)A.width, Hd = (int)A.height;
-    int out_row = y;
-    if (A.compact && sharded)
-        out_row = (int)((((uint32_t)y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
-                        (uint32_t)y % (uint32_t)A.strip_rows);
-    PixelSink sink{A, out_row, A.fb, A.color_aov};
-
-    // camera ray (getRayDirection / getRayDirectionOrtho, Renderer.cu:44-70)
-    const float u = (float)x / (float)Wd, v = (float)y / (float)Hd;
-    f3 origin = A.origin;
-    f3 ray;
-    if (A.ortho) {
-        ray = A.fwd;
-        origin = origin + ((A.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
-        origin = origin + (A.up * (v * 2 - 1)) * A.ortho_y;
-    } else {
-        float su = u * 2 - 1, sv = v * 2 - 1;
-        ray.x = A.fwd.x + su * A.kx * A.right.x + sv * A.ky * A.up.x;
-        ray.y = A.fwd.y + su * A.kx * A.right.y + sv * A.ky * A.up.y;
-        ray.z = A.fwd.z + su * A.kx * A.right.z + sv * A.ky * A.up.z;
-        ray = unit3(ray);
-    }
-
-    TraceResult pr;
-    unsigned long long* const bh = (STATS && A.stats) ? A.stats + kStatBrickHist : nullptr;  // (experiments build diagnostics)
-    trace_wave<STATS>(A.W, kMaxSteps, live, origin, ray, pr, cnt, nullptr, nullptr, false, bh);
-    n_primary = live ? 1u : 0u;
-    const bool hit = live && pr.hit;
-    n_hits = hit ? 1u : 0u;
-    const f3 normal = mk3(-pr.normal.x, -pr.normal.y, -pr.normal.z);
-    const f3 position = pr.pos;
-    const bool lit = hit && A.mode == 0;  // lanes that run calculateColor (Renderer.cu:90-168)
-
-    // shadow ray (Renderer.cu:97-102), entered by the whole wave
-    const f3 L = A.light_dir;
-    const f3 sray = A.light_unit;
-    bool shadowed = false;
-    if (A.shadow) {
-        TraceResult ts;
-        trace_wave<STATS>(A.W, kMaxSteps, lit, position + sray * 0.01f, sray, ts, cnt, nullptr, nullptr, false, bh);
-        shadowed = lit && ts.hit;
-        n_shadow = lit ? 1u : 0u;
-    }
-    const float l_dot = hi(dot3(normal, L), 0) * (float)(shadowed ? 0 : 1);
-    f3 color = mk3(0, 0, 0);
-    {
-        f3 diffuse = A.light_color * l_dot;
-        float up_dot = normal.x * 0.0f + normal.y * 1.0f + normal.z * 0.0f;
-        float t = (float)((double)up_dot * 0.5 + 0.5);
-        color = diffuse + A.ambient * (0.25f + t * (1.0f - 0.25f));
-        if (!shadowed) {
-            f3 view = unit3(position - origin);
-            f3 refl = reflect3(L, normal);
-            float spec = pow32(hi(dot3(view, refl), 0));
-            color.x += spec * A.light_color.x;
-            color.y += spec * A.light_color.y;
-            color.z += spec * A.light_color.z;
-        }
-    }
-    // occlusion / bounce samples (Renderer.cu:121-165)
-    const bool gate = lit && (l_dot == 0 || A.bounce_all_hits);
-    {
-        const int samples = A.bounce_samples;
-        const uint32_t seed = ty * A.width + tx;
-        float occl = 0.0f;
-        for (int i = 0; i < samples; ++i) {
-            uint32_t si = seed + (uint32_t)i * 1000u + (A.frame_number + 1u) * 1000u;
-            f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
-            sd = unit3(sd);
-            if (dot3(sd, normal) < 0)
-                sd = reflect3(sd, normal);
-            TraceResult tb;
-            trace_wave<STATS>(A.W, 8, gate, position + normal * 0.01f, sd, tb, cnt, nullptr, nullptr, false, bh);
-            if (gate) {
-                n_bounce += 1;
-                if (!tb.hit)
-                    occl += 1.0f;
-            }
-            if (A.bounce_depth >= 2) {  // extension: second bounce from the sample ray's hit point
-                const bool again = gate && tb.hit;
-                const f3 n2 = mk3(-tb.normal.x, -tb.normal.y, -tb.normal.z);
-                const uint32_t s2 = si + 500u;
-                f3 d2 = mk3(random_float(s2) * 2 - 1, random_float(s2 * 10u) * 2 - 1, random_float(s2 * 100u) * 2 - 1);
-                d2 = unit3(d2);
-                if (dot3(d2, n2) < 0)
-                    d2 = reflect3(d2, n2);
-                TraceResult t2;
-                trace_wave<STATS>(A.W, 8, again, tb.pos + n2 * 0.01f, d2, t2, cnt, nullptr, nullptr, false, bh);
-                if (again) {
-                    n_bounce += 1;
-                    if (!t2.hit)
-                        occl += 0.5f;
-                }
-            }
-        }
-        if (gate) {
-            if (samples > 0)
-                occl /= (float)samples;
-            else
-                occl = 1.0f;
-            color = color * occl;
-        }
-    }
-
-    if (live) {
-        if (A.hit_aov)
-            A.hit_aov[(size_t)out_row * A.width + (size_t)x] =
-                pr.hit ? (long long)pr.vx + (long long)A.W.X * ((long long)pr.vy + (long long)A.W.Y * (long long)pr.vz)
-                       : -1ll;
-        if (pr.hit) {
-            if (A.mode == 1) {  // DEBUG_VIEW quadrants, Renderer.cu:215-243
-                f3 dv = pr.pos - origin;
-                float dist = sqrtf(dot3(dv, dv));
-                const float wrap = (float)(1.0 + 1e-6);
-                f3 hp = mk3(fmodf(pr.pos.x / 128.0f, wrap), fmodf(pr.pos.y / 128.0f, wrap),
-                            fmodf(pr.pos.z / 128.0f, wrap));
-                if (x < (Wd >> 1) && y < (Hd >> 1))
-                    sink.put(x, y, normal);
-                else if (x >= (Wd >> 1) && y < (Hd >> 1))
-                    sink.put(x, y, hp);
-                else if (x < (Wd >> 1)) {
-                } else
-                    sink.put(x, y, mk3(dist * 0.01f, 0, 0));
-            } else {
-                if (A.accum)
-                    color = accumulate_color(A, out_row, x, color);
-                f3 c = mk3(color.x / (color.x + 1.0f), color.y / (color.y + 1.0f), color.z / (color.z + 1.0f));  // Tonemap
-                c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
-                sink.put(x, y, c);
-            }
-        } else {
-            sink.put(x, y, ray);
-        }
-        if (tx == (A.width >> 1) && ty == (A.height >> 1))
-            sink.put(x, y, mk3(10, 10, 10));
-        if (A.mode == 1 && x < (Wd >> 1) && y > (Hd >> 1))
-            sink.put(x, y, mk3((float)pr.steps / 256.0f, 0, 0));
-    }
-
-    unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_bounce),
-                       s3 = wave_sum(n_hits);
-    if (lane == 0 && A.stats) {
-        atomicAdd(&A.stats[kStatPrimary], s0);
-        atomicAdd(&A.stats[kStatShadow], s1);
-        atomicAdd(&A.stats[kStatBounce], s2);
-        atomicAdd(&A.stats[kStatPrimaryHits], s3);
-    }
-    if (STATS) {
-        unsigned long long p0 = wave_sum(cnt.coarse_probes), p1 = wave_sum(cnt.brick_entries),
-                           p2 = wave_sum(cnt.fine_probes);
-        if (lane == 0 && A.stats) {
-            atomicAdd(&A.stats[kStatCoarseProbes], p0);
-            atomicAdd(&A.stats[kStatBrickEntries], p1);
-            atomicAdd(&A.stats[kStatFineProbes], p2);
-            atomicAdd(&A.stats[kStatDbgIters], (unsigned long long)cnt.iters);
-            atomicAdd(&A.stats[kStatDbgWalkLanes], (unsigned long long)cnt.walk_lanes);
-            atomicAdd(&A.stats[kStatDbgEndRuns], (unsigned long long)cnt.end_runs);
-            atomicAdd(&A.stats[kStatDbgBoxRuns], (unsigned long long)cnt.box_runs);
-        }
-    }
-}
-
-#endif  // VXRT_EXPERIMENTS
-
-template <bool STATS>
-__global__ __launch_bounds__(256) void k_trace_batch_wave(BatchArgs B)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    RayCounters cnt = {0, 0, 0};
-    const bool live = i < B.n;
-    const unsigned long long j = live ? i : 0ull;
-    f3 o = mk3(B.origins[3 * j], B.origins[3 * j + 1], B.origins[3 * j + 2]);
-    f3 d = mk3(B.dirs[3 * j], B.dirs[3 * j + 1], B.dirs[3 * j + 2]);
-    TraceResult t;
-    // an invalid ray (include/vxrt.h, ray validity) is not traced: the tracer's initial state reads as a miss with 0 steps
-    trace_wave<STATS, true>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, cnt, (STATS && i == 0) ? B.dbg_trace : nullptr);
-    if (live) {
-        f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
-        B.pos[3 * i] = p.x;
-        B.pos[3 * i + 1] = p.y;
-        B.pos[3 * i + 2] = p.z;
-        B.normal[3 * i] = t.normal.x;
-        B.normal[3 * i + 1] = t.normal.y;
-        B.normal[3 * i + 2] = t.normal.z;
-        B.steps[i] = t.steps;
-        if (B.hit)
-            B.hit[i] = t.hit ? 1 : 0;
-        if (B.voxel)
-            B.voxel[i] = t.hit ? (long long)t.vx + (long long)B.W.X * ((long long)t.vy + (long long)B.W.Y * (long long)t.vz)
-                               : -1ll;
-    }
-    if (STATS && B.stats) {
-        const int lane = threadIdx.x & 63;
-        unsigned long long r = wave_sum(live ? 1u : 0u), h = wave_sum(live && t.hit ? 1u : 0u),
-                           p0 = wave_sum(cnt.coarse_probes), p1 = wave_sum(cnt.brick_entries),
-                           p2 = wave_sum(cnt.fine_probes);
-        if (lane == 0) {
-            atomicAdd(&B.stats[kStatPrimary], r);
-            atomicAdd(&B.stats[kStatPrimaryHits], h);
-            atomicAdd(&B.stats[kStatCoarseProbes], p0);
-            atomicAdd(&B.stats[kStatBrickEntries], p1);
-            atomicAdd(&B.stats[kStatFineProbes], p2);
-        }
-    }
-}
-
 }  // namespace vxrt
 
-#include "vxrt_persist.hpp"
-#include "vxrt_persist_lds.hpp"
 #include "vxrt_persist2.hpp"
 
 namespace vxrt {
 
-// The batch query on the tracer of vxrt_wave2.hpp (kernel variant 7): one ray per lane, the tracer's cold fields in LDS.
-// It exists so that the batch tests and the randomised parity runs reach that tracer with caller-made rays.
+// The batch query one ray per lane, the tracer's cold fields in LDS: what batches too small for the persistent queue take
+// (BASELINE configs[0]'s million-ray fan: 17.7 Grays/s against 16.6 for the straightforward loops, tools/batch_probe.py).
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
 {
@@ -626,184 +390,61 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
 
 }  // namespace vxrt
 
-#ifdef VXRT_EXPERIMENTS
-#include "vxrt_pool.hpp"  // variant 3: A/B builds only
-#endif
 #include "vxrt_batch_persist.hpp"
-#include "vxrt_ts.hpp"
 
 namespace vxrt {
 
-// generations of a traversal/shading launch: primary, shadow, bounce samples (each possibly followed by its second bounce)
-int ts_generations(const RenderArgs& A)
-{
-    if (A.mode != 0)
-        return 1;  // the debug view stores every pixel after its primary ray
-    return 1 + (A.shadow ? 1 : 0) + (A.bounce_samples > 0 ? A.bounce_samples * (A.bounce_depth >= 2 ? 2 : 1) : 0);
-}
-
-// Variant 6: the wavefront pipeline of vxrt_ts.hpp.  One stream, kernels in generation order:
-//   gen | T(0) S(0) | T(1) S(1) | ... ; queue lengths stay on the device (group ray counts), no host round trip.
-// (Measured and removed: cutting the groups into 2-32 parts run as independent chains on 2-4 forked streams, so that one
-// chain's T would fill the other's low-occupancy tail and the bandwidth-bound S kernels would run beside a T.  Chains that
-// do the same work stay in lockstep -- every T is a persistent grid of the whole chip, so two of them split the wave slots
-// instead of following each other -- and more, smaller launches pay more ramps and tails than they hide: 1 / 2 / 4 streams
-// x 1 / 4 / 16 parts = 14.7 / 15.0 / 19.0 ms per 16-view step, 16 parts on one stream 31.9.  Two chains STAGGERED by one
-// traversal (the second chain's first T waits for the first chain's, so that one chain traces while the other shades):
-// 14.88 ms against 14.60 with one chain.  profiles/r03_ts_pipeline.md.)
-hipError_t launch_render_ts(const RenderArgs& A, const TsArgs& S, bool stats, hipStream_t stream)
-{
-    static_assert(kTsShards == VXRT_TS_SHARDS, "queue shards");
-    const int gens = ts_generations(A);
-    if (S.groups == 0)
-        return hipSuccess;
-    hipError_t e = hipMemsetAsync(S.tickets, 0, (size_t)gens * kTsShards * 64u * sizeof(unsigned int), stream);
-    if (e != hipSuccess)
-        return e;
-    const unsigned cus = std::max(1u, A.persistent_waves / 16u);  // (persistent_waves = 16 per CU unless a test shrank the grid)
-    const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
-    // S: one wave per group, 4 waves per block, at most 8 resident blocks' worth per CU (the loops stride over the groups)
-    const unsigned s_blocks = (unsigned)std::min<unsigned long long>(((unsigned long long)S.groups + 3ull) / 4ull, (unsigned long long)cus * 8ull);
-    const unsigned t_waves = (unsigned)std::min<unsigned long long>((unsigned long long)S.groups, (unsigned long long)cus * 4ull * VXRT_TS_OCC);
-    hipLaunchKernelGGL(k_ts_gen, dim3(s_blocks), dim3(256), 0, stream, A, S);
-    for (int g = 0; g < gens; ++g) {
-        TsTraceArgs B;
-        B.W = A.W;
-        B.rays = S.rays[g & 1];
-        B.gcount = S.gcount[g & 1];
-        B.res = S.res;
-        B.res_voxel = g == 0 ? S.res_voxel : nullptr;
-        B.ticket = S.tickets + (size_t)g * kTsShards * 64u;
-        B.groups = S.groups;
-        B.stats = A.stats;
-        if (stats)
-            hipLaunchKernelGGL(k_ts_trace<true>, dim3(t_waves), dim3(64), 0, stream, B);
-        else
-            hipLaunchKernelGGL(k_ts_trace<false>, dim3(t_waves), dim3(64), 0, stream, B);
-        if (second_bounce)
-            hipLaunchKernelGGL(k_ts_shade<true>, dim3(s_blocks), dim3(256), 0, stream, A, S, g);
-        else
-            hipLaunchKernelGGL(k_ts_shade<false>, dim3(s_blocks), dim3(256), 0, stream, A, S, g);
-    }
-    return hipGetLastError();
-}
-
-// The kernel a render launch runs: variant 0 = wave state machine, one lane per pixel; 1 = straightforward per-lane loops
-// (A/B and cross-check); 2 = persistent waves pulling pixels from a tile queue (k_render_persist); 3 = the same with the
-// pixel chains pooled in LDS (k_render_pool); 5 = k_render_persist with its cold state in LDS, 5 waves per SIMD
-// (k_render_persist_lds); 4 = the default, resolved per launch from measurements on one MI355X (profiles/r02_mechanisms_ab.md):
-//   * several views in one launch: 5 (5.12 Grays/s on the bench workload against 5.07 for the pool kernel and 4.88 for the
-//     pixel-per-lane kernel; +3 % on 4K frames, +1 % on the 16k world, equal within 0.3 % on the small configurations);
-//   * one view: 5 when the launch is large -- at least 4 M rays counting one shadow and one bounce ray per pixel where
-//     enabled (a 1080p frame with secondary rays: -1 % launched alone, +4.7 % with two frames in flight; 4K frames +3 % /
-//     +5 %) -- and 2 for small launches (1080p primary rays only: the 5-wave grid's longer ramp costs 8 % there).
+// The kernel a render launch runs (vxrt_set_kernel_variant): 7 = the persistent kernel of vxrt_persist2.hpp, 1 = the
+// straightforward per-lane loops (cross-check), 4 = the default, which is 7 for every launch shape and world.
 int resolve_render_variant(const RenderArgs& A, int variant)
 {
-    if (variant == 4) {
-        const unsigned long long rays = (unsigned long long)A.width * A.launch_rows *
-                                        (1ull + (A.shadow ? 1ull : 0ull) + (A.bounce_samples > 0 ? 1ull : 0ull));
-        variant = (A.nviews >= 2 || rays >= 4000000ull) ? 7 : 2;  // (7 falls back to 5 below if the world does not fit it)
-    }
-#ifdef VXRT_EXPERIMENTS
-    if (variant == 3 && (A.bounce_samples > kPoolMaxSamples || A.width > 65535u))
-        variant = 2;  // the pool kernel packs the sample counter and the launch column into its slot words
-#else
-    if (variant == 0 || variant == 3)
-        variant = 2;  // (not in this build; vxrt_set_kernel_variant refuses them)
-#endif
-    if (variant == 7 && !tracer2_fits(A.W))
-        variant = 5;  // (vxrt_wave2.hpp packs the steps left to the grid's faces into 11 + 10 + 11 bits)
-    if (variant == 6) {  // the wavefront pipeline indexes pixels and queue slots with 32 bits and keeps a queue per generation
-        const unsigned long long nv = A.nviews ? A.nviews : 1u;
-        const unsigned long long slots = (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * 64ull * nv;
-        if (slots >= (1ull << 31) || ts_generations(A) > (int)kTsMaxGenerations || A.bounce_samples >= (1 << 24))
-            variant = 5;
-    }
-    return variant;
+    (void)A;
+    return variant == 1 ? 1 : 7;
 }
 
-hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream, const TsArgs* ts)
+// The persistent grid of a launch.  A full grid is 5 waves per SIMD; launches with few tiles per wave are started with a
+// smaller one, so that every wave still takes several tiles through the queue (its balance) -- see launch_render.
+static unsigned render_grid_waves(const RenderArgs& A, unsigned long long ntiles)
 {
-    // one wave per workgroup: no wave waits for a slower sibling before its slot is reused (+5 % measured)
-#ifdef VXRT_EXPERIMENTS
-    static const int threads = getenv("VXRT_BLOCK") ? atoi(getenv("VXRT_BLOCK")) : 64;
-#else
-    constexpr int threads = 64;
-#endif
-    const unsigned tile = threads == 64 ? 8u : 16u;
-    dim3 block(threads == 64 ? 64 : 256, 1, 1);
-    dim3 grid((A.width + tile - 1) / tile, (A.launch_rows + tile - 1) / tile, 1);
-    if (grid.x == 0 || grid.y == 0)
+    const unsigned resident = std::max(1u, A.persistent_waves / 4u * (unsigned)VXRT_PERSIST2_OCC);
+    return (unsigned)std::min<unsigned long long>(ntiles, resident);
+}
+
+hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)
+{
+    if (A.width == 0 || A.launch_rows == 0)
         return hipSuccess;
-#ifdef VXRT_EXPERIMENTS
-    static const int lds = getenv("VXRT_LDS") ? atoi(getenv("VXRT_LDS")) : 0;  // occupancy experiments only
-#else
-    constexpr int lds = 0;
-#endif
     variant = resolve_render_variant(A, variant);
-    if (variant == 6) {
-        if (ts)
-            return launch_render_ts(A, *ts, stats, stream);
-        variant = 5;  // (no workspace was leased: cannot happen through vxrt_api.hip)
-    }
-    if (variant == 2 || variant == 3 || variant == 5 || variant == 7) {
-        const unsigned long long ntiles =
-            (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
-        // persistent_waves = 4 per SIMD; variant 5's kernel is built for VXRT_PERSIST_LDS_OCC
-        const unsigned resident = std::max(1u, variant == 5   ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST_LDS_OCC
-                                               : variant == 7 ? A.persistent_waves / 4u * (unsigned)VXRT_PERSIST2_OCC
-                                                              : A.persistent_waves);
-        const unsigned waves = ntiles < resident ? (unsigned)ntiles : resident;
-        const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
-        if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
-            return e;
-        const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
-        const dim3 g(waves), b(64);
-#ifdef VXRT_EXPERIMENTS
-#define VXRT_LAUNCH_POOL(S, B2, M) hipLaunchKernelGGL((k_render_pool<S, B2, M>), g, b, 0, stream, A)
-#else
-#define VXRT_LAUNCH_POOL(S, B2, M) (void)0
-#endif
-#define VXRT_LAUNCH_PERSIST(S, B2, M)                                                        \
-    do {                                                                                     \
-        if (variant == 3)                                                                    \
-            VXRT_LAUNCH_POOL(S, B2, M);                                                      \
-        else if (variant == 5)                                                               \
-            hipLaunchKernelGGL((k_render_persist_lds<S, B2, M>), g, b, 0, stream, A);        \
-        else if (variant == 7)                                                               \
-            hipLaunchKernelGGL((k_render_persist2<S, B2, M>), g, b, 0, stream, A);           \
-        else                                                                                 \
-            hipLaunchKernelGGL((k_render_persist<S, B2, M>), g, b, lds, stream, A);          \
-    } while (0)
-        if (A.nviews) {
-            if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, true);
-            else if (stats) VXRT_LAUNCH_PERSIST(true, false, true);
-            else if (second_bounce) VXRT_LAUNCH_PERSIST(false, true, true);
-            else VXRT_LAUNCH_PERSIST(false, false, true);
-        } else {
-            if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, false);
-            else if (stats) VXRT_LAUNCH_PERSIST(true, false, false);
-            else if (second_bounce) VXRT_LAUNCH_PERSIST(false, true, false);
-            else VXRT_LAUNCH_PERSIST(false, false, false);
-        }
-#undef VXRT_LAUNCH_PERSIST
-#undef VXRT_LAUNCH_POOL
+    if (variant == 1) {
+        // one wave per workgroup: no wave waits for a slower sibling before its slot is reused
+        const dim3 block(64, 1, 1), grid((A.width + 7u) / 8u, (A.launch_rows + 7u) / 8u, 1);
+        if (stats)
+            hipLaunchKernelGGL(k_render<true>, grid, block, 0, stream, A);
+        else
+            hipLaunchKernelGGL(k_render<false>, grid, block, 0, stream, A);
         return hipSuccess;
     }
-    if (variant == 1) {
-        if (stats)
-            hipLaunchKernelGGL(k_render<true>, grid, block, lds, stream, A);
-        else
-            hipLaunchKernelGGL(k_render<false>, grid, block, lds, stream, A);
+    const unsigned long long ntiles =
+        (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
+    const unsigned waves = render_grid_waves(A, ntiles);
+    const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
+        return e;
+    const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
+    const dim3 g(waves), b(64);
+#define VXRT_LAUNCH_PERSIST(S, B2, M) hipLaunchKernelGGL((k_render_persist2<S, B2, M>), g, b, 0, stream, A)
+    if (A.nviews) {
+        if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, true);
+        else if (stats) VXRT_LAUNCH_PERSIST(true, false, true);
+        else if (second_bounce) VXRT_LAUNCH_PERSIST(false, true, true);
+        else VXRT_LAUNCH_PERSIST(false, false, true);
+    } else {
+        if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, false);
+        else if (stats) VXRT_LAUNCH_PERSIST(true, false, false);
+        else if (second_bounce) VXRT_LAUNCH_PERSIST(false, true, false);
+        else VXRT_LAUNCH_PERSIST(false, false, false);
     }
-#ifdef VXRT_EXPERIMENTS
-    else {
-        if (stats)
-            hipLaunchKernelGGL(k_render_wave<true>, grid, block, lds, stream, A);
-        else
-            hipLaunchKernelGGL(k_render_wave<false>, grid, block, lds, stream, A);
-    }
-#endif
+#undef VXRT_LAUNCH_PERSIST
     return hipSuccess;
 }
 
@@ -813,44 +454,33 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
         return hipSuccess;
     dim3 block(256, 1, 1);
     dim3 grid((unsigned)((B.n + 255) / 256), 1, 1);
-    // default: persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the
-    // persistent grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
-    const bool persistent = variant >= 2 && variant != 7 && B.ticket && !B.dbg_trace && B.persistent_waves &&
-                            B.n >= 8ull * 64ull * B.persistent_waves;  // (render variants 2..6 are all 'persistent' for a batch)
-    // One ray per lane on the tracer of vxrt_wave2.hpp: variant 7 always (so that tests reach that tracer with batches of any
-    // size), and what every persistent variant but 2 takes for batches too small for the queue -- BASELINE configs[0]'s
-    // million-ray fan: 17.7 Grays/s against 14.0 for k_trace_batch_wave and 16.6 for the straightforward loops
-    // (tools/batch_probe.py).  Variant 2 keeps the first tracer (tests and randomised parity run both).
-    if ((variant == 7 || (variant >= 3 && !persistent)) && !B.dbg_trace && tracer2_fits(B.W)) {
+    if (variant == 1) {  // the straightforward loops (cross-check)
+        if (stats)
+            hipLaunchKernelGGL(k_trace_batch<true>, grid, block, 0, stream, B);
+        else
+            hipLaunchKernelGGL(k_trace_batch<false>, grid, block, 0, stream, B);
+        return hipSuccess;
+    }
+    // persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the persistent
+    // grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
+    const unsigned resident = B.persistent_waves / 4u * (unsigned)VXRT_BATCH_OCC;
+    const bool persistent = B.ticket && resident && B.n >= 8ull * 64ull * resident;
+    if (!persistent) {
         if (stats)
             hipLaunchKernelGGL(k_trace_batch_wave2<true>, grid, block, 0, stream, B);
         else
             hipLaunchKernelGGL(k_trace_batch_wave2<false>, grid, block, 0, stream, B);
         return hipSuccess;
     }
-    if (persistent) {
-        const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
-        if (e != hipSuccess)
-            return e;
-        const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
-        const dim3 g((unsigned)(tickets < B.persistent_waves ? tickets : B.persistent_waves)), b(64);
-        if (stats)
-            hipLaunchKernelGGL(k_trace_batch_persist<true>, g, b, 0, stream, B);
-        else
-            hipLaunchKernelGGL(k_trace_batch_persist<false>, g, b, 0, stream, B);
-        return hipSuccess;
-    }
-    if (variant == 1) {
-        if (stats)
-            hipLaunchKernelGGL(k_trace_batch<true>, grid, block, 0, stream, B);
-        else
-            hipLaunchKernelGGL(k_trace_batch<false>, grid, block, 0, stream, B);
-    } else {
-        if (stats)
-            hipLaunchKernelGGL(k_trace_batch_wave<true>, grid, block, 0, stream, B);
-        else
-            hipLaunchKernelGGL(k_trace_batch_wave<false>, grid, block, 0, stream, B);
-    }
+    const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess)
+        return e;
+    const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
+    const dim3 g((unsigned)(tickets < resident ? tickets : resident)), b(64);
+    if (stats)
+        hipLaunchKernelGGL(k_trace_batch_persist<true>, g, b, 0, stream, B);
+    else
+        hipLaunchKernelGGL(k_trace_batch_persist<false>, g, b, 0, stream, B);
     return hipSuccess;
 }
 

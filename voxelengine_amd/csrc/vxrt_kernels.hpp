@@ -26,15 +26,7 @@ enum StatSlot {
     kStatDbgDrained,    // persistent kernel: iterations after the tile queue ran dry
     kStatDbgNextTicks,  // persistent kernel: 100 MHz ticks inside the ray-finished phase, summed over waves
     kStatDbgParkTicks,  // ... inside the box and end-of-walk phases
-    // Experiments build, probe-counting launches: histogram over wave-loop iterations of the number of DISTINCT bricks among
-    // the lanes that walk inside a brick in that iteration (bins 0..64), for primary-, shadow- and bounce-stage lanes kept
-    // apart where the kernel knows the stage (the fused kernels; T and the wave kernel count everything under "all")
-    kStatBrickHist,
-    kStatBrickHistEnd = kStatBrickHist + 65,
-    // ... and the same histogram over the iterations in which NO lane walks on the coarse grid (every occupancy word of the
-    // iteration's probes comes from those n bricks: what a wave-level brick cache of n entries could serve alone)
-    kStatBrickHistFineOnly = kStatBrickHistEnd,
-    kStatCount = kStatBrickHistFineOnly + 65
+    kStatCount
 };
 
 constexpr unsigned kMaxScheduledTileRows = 512;  // frames up to 4096 launch rows get a tile schedule
@@ -71,9 +63,8 @@ struct RenderArgs {
     unsigned int nviews;
     float4* accum;       // temporal accumulation history (vxrt_render_flags.d_accum), single-view launches only, or NULL
     int accum_reset;
-    int want_hit_aov;  // some view of the launch has a hit-index AOV (the pool kernel keeps the voxel in the pixel's slot then)
+    int want_hit_aov;  // some view of the launch has a hit-index AOV
     f3 light_unit;  // normalize(light_dir), the shadow ray (Renderer.cu:97): the same IEEE operations, evaluated once on the host
-                    // (k_render_persist_lds; appended, so that the other kernels' argument layout is what it was)
     f3 light_step;           // light_unit * 0.01f (the shadow ray's offset, Renderer.cu:97)
     float bounce_samples_f;  // (float)bounce_samples
 };
@@ -101,32 +92,9 @@ struct BatchArgs {
     uint8_t* hit;
     long long* voxel;
     unsigned long long* stats;
-    unsigned int* dbg_trace;  // development: per-iteration state of ray 0 (probe-counting variant only), or NULL
     unsigned int* ticket;     // persistent batch kernel: next 64-ray ticket of the queue (zeroed per launch), or NULL
     unsigned int persistent_waves;
     int max_steps;            // Raytrace's maxSteps (VolumeRaytracer.cu:354,386); kMaxSteps unless the caller lowered it
-};
-
-constexpr unsigned kTsShards = 16;  // counters per queue (VXRT_TS_SHARDS, vxrt_ts.hpp)
-constexpr unsigned kTsMaxGenerations = 64;  // primary + shadow + bounce_samples * bounce_depth must fit (else the fused kernel runs)
-constexpr uint32_t kTsNoRay = 0xFFFFFFFFu;
-
-// The HBM workspace of one launch (carved from a per-context ring slot, vxrt_api.hip).  Everything is keyed by PIXEL SLOT:
-// slot = view * slots_per_view + tile * 64 + pixel of the 8x8 tile, tiles in the launch's hand-out order.  A GROUP is the
-// 64 slots of one tile; a generation's rays are compacted INSIDE their group (a wave of S writes the rays of its group
-// back to back at the group's base and the group's ray count: ballots only, no global atomic), so all arrays are read and
-// written with whole-wave contiguous accesses and the traversal kernel's queue is "the groups in order".
-struct TsArgs {
-    uint4* rays[2];           // prepared ray records, 4 x uint4 per slot: generation g reads rays[g & 1], S writes the next one's
-    uint8_t* idx[2];          // per ray (group base + rank): the pixel of the ray, as its index in the group (0..63)
-    uint32_t* gcount[2];      // per group: rays of the generation in that group
-    uint4* res;               // one result per ray (group base + rank): {hit | normal code << 1 | steps << 4, position}
-    long long* res_voxel;     // primary generation, when some view has a hit-index AOV: the hit voxel index per ray; or NULL
-    uint4* pstate;            // 2 x uint4 per pixel slot: {primary hit position, stage | primary normal code << 3 | sample << 6}, {colour, occlusion sum}
-    unsigned int* tickets;    // generation g's queue heads: kTsShards counters, 64 words apart (a cache line each), from
-                              // tickets[g * kTsShards * 64]; zeroed per launch
-    uint32_t slots_per_view;  // 64 * tiles of the launch grid
-    uint32_t groups;          // slots_per_view / 64 * views
 };
 
 }  // namespace vxrt

@@ -1,30 +1,159 @@
-// vxrt_persist2.hpp -- k_render_persist_lds (vxrt_persist_lds.hpp) on the tracer of vxrt_wave2.hpp (kernel variant 7).
+// vxrt_persist2.hpp -- screenDispatch (VoxelRT/Renderer.cu:179-276) as a persistent wave-level kernel: k_render_persist2,
+// the render kernel of the product (kernel variant 7; variant 1, k_render in vxrt_kernels.hip, is the straightforward
+// cross-check).
 //
-// The same persistent kernel, statement for statement -- one pixel chain per lane, tile queue, parked phases voted, cold
-// state in the wave's LDS block -- with the traversal replaced by WaveTracer2: speculative exec-masked DDA advance, packed
-// step counters instead of cell coordinates, no crossing point in the probe (profiles/r03_instr_cost.md: the vector ALU
-// pipe is what bounds these kernels, and a probe pair of the old tracer is 373 cycles of it, of the new one ~165).
+// The per-pixel ray chain of the reference -- primary ray, shadow ray for a hit (Renderer.cu:97-102), occlusion /
+// bounce samples (:121-165), shading, tonemap, store -- is a dependent sequence per pixel but independent across
+// pixels.  Launching "one lane = one pixel, three trace loops one after the other" leaves most lanes idle: measured
+// useful-lane share of the traversal loop was ~46 % (rays of one 8x8 tile differ in length, sky pixels have no
+// secondary rays, bounce rays go everywhere).  Here a wavefront is persistent:
+//
+//   * the launch grid's 8x8 pixel tiles are a queue (one global atomic per 64 pixels);
+//   * each lane carries ONE pixel through its whole chain inside the single traversal loop of vxrt_wave2.hpp; the
+//     moment its chain ends it stores the pixel and takes the next pixel from the wave's current tile
+//     (ranks from the ballot mask, no per-lane atomics), so all 64 lanes stay in the walk phase;
+//   * "ray finished" is one more parked state (ST_DONE), voted like the box/end phases: the per-pixel work (camera
+//     ray, shading, next ray set-up with its divisions and square root) runs for many lanes at once;
+//   * the state only the parked phases touch -- the tracer's cold fields, the pixel's chain state, the wave's four ray
+//     counters -- lives in the wave's LDS block (25 columns of 64 dwords, 6.4 KB per wave), and the view's buffer pointers
+//     are fetched where they are used: the probe loop fits 96 VGPRs = 5 waves per SIMD (20 per CU, 128 KB of 160 KB LDS).
+//
+// Results are identical to the one-lane-one-pixel kernel: every pixel is a pure function of its inputs.
 // The STATS instantiation counts the probes of SURVEY 8(d) (WaveTracer2 derives them from its packed step counters at the
 // end of each walk, so the probes themselves are the timed kernel's) and collects the loop diagnostics.
 #pragma once
 
-#include "vxrt_persist_lds.hpp"
+#include "vxrt_kernels.hpp"
 #include "vxrt_wave2.hpp"
 
 namespace vxrt {
 
+enum : uint32_t { PX_NONE = 0u, PX_PRIMARY = 1u, PX_SHADOW = 2u, PX_BOUNCE = 3u, PX_BOUNCE2 = 4u };
+
+struct PixelCoords {
+    uint32_t tx, ty;  // launch coordinates of the reference's thread (crosshair, RNG seed)
+    int x, y;         // frame pixel
+    int out_row;      // row in the destination buffers
+    bool live;
+};
+
+// launch (tx,row) -> pixel (Renderer.cu:183-196 + this build's strip sharding)
+__device__ __forceinline__ PixelCoords pixel_coords(const RenderArgs& A, uint32_t frame_number, uint32_t tx, uint32_t row)
+{
+    PixelCoords c;
+    c.tx = tx;
+    c.ty = row;
+    c.x = (int)tx;
+    const bool sharded = A.strip_count > 1;
+    if (sharded && !A.checkerboard) {
+        // A shard's launch rows are its own frame rows in order: launch row = packed row, the frame row follows from
+        // the strip arithmetic, and ownership holds by construction -- no division by the strip count, and none by the
+        // strip height when it is a power of two (strip_shift >= 0; the default 16 is).
+        const uint32_t sr = (uint32_t)A.strip_rows;
+        const uint32_t q = A.strip_shift >= 0 ? row >> A.strip_shift : row / sr;
+        c.ty = (q * (uint32_t)A.strip_count + (uint32_t)A.strip_index) * sr + (row - q * sr);
+        c.y = (int)c.ty;
+        c.live = row < A.launch_rows && (uint32_t)c.x < A.width && (uint32_t)c.y < A.height;
+        c.out_row = A.compact ? (int)row : c.y;
+        return c;
+    }
+    c.live = row < A.launch_rows;
+    c.y = (int)c.ty;
+    if (A.checkerboard) {
+        c.y *= 2;
+        if ((c.x % 2) == 0)
+            c.y += 1;
+        if (frame_number % 2 == 0)
+            c.y += 1;
+    }
+    c.live = c.live && (uint32_t)c.x < A.width && (uint32_t)c.y < A.height;
+    if (c.live && sharded && ((uint32_t)c.y / (uint32_t)A.strip_rows) % (uint32_t)A.strip_count != (uint32_t)A.strip_index)
+        c.live = false;
+    c.out_row = c.y;
+    if (A.compact && sharded)
+        c.out_row = (int)((((uint32_t)c.y / (uint32_t)A.strip_rows) / (uint32_t)A.strip_count) * (uint32_t)A.strip_rows +
+                          (uint32_t)c.y % (uint32_t)A.strip_rows);
+    return c;
+}
+
+// the per-view inputs of one lane's pixel: kernel arguments for a single-view launch, loaded from the launch's
+// ViewArgs array for a multi-view one
+struct LaneView {
+    f3 origin, fwd, up, right;
+    uint32_t frame_number;
+    uint8_t* fb;
+    float* color_aov;
+    long long* hit_aov;
+};
+
+// getRayDirection / getRayDirectionOrtho (Renderer.cu:44-70)
+__device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& V, int x, int y, f3& origin, f3& ray)
+{
+    const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
+    origin = V.origin;
+    if (A.ortho) {
+        ray = V.fwd;
+        origin = origin + ((V.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+        origin = origin + (V.up * (v * 2 - 1)) * A.ortho_y;
+    } else {
+        float su = u * 2 - 1, sv = v * 2 - 1;
+        ray.x = V.fwd.x + su * A.kx * V.right.x + sv * A.ky * V.up.x;
+        ray.y = V.fwd.y + su * A.kx * V.right.y + sv * A.ky * V.up.y;
+        ray.z = V.fwd.z + su * A.kx * V.right.z + sv * A.ky * V.up.z;
+        ray = unit3(ray);
+    }
+}
+
+// the ray origin alone (perspective: the camera; ortho: per pixel) -- what shading and the debug view need of a
+// pixel's camera ray once the primary ray has been traced
+__device__ __forceinline__ f3 camera_origin(const RenderArgs& A, const LaneView& V, int x, int y)
+{
+    f3 origin = V.origin;
+    if (A.ortho) {
+        const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
+        origin = origin + ((V.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
+        origin = origin + (V.up * (v * 2 - 1)) * A.ortho_y;
+    }
+    return origin;
+}
+
+enum : int { PF_STAGE = 0, PF_TX, PF_ROW, PF_POS_X, PF_POS_Y, PF_POS_Z, PF_COL_X, PF_COL_Y, PF_COL_Z, PF_PCODE, PF_PSTEPS, PF_OCCL,
+             PF_SAMPLE, PF_PIXEL_FIELDS };
+// The launch's arguments as the ray-finished phase reads them.  The ~50 frame arguments (camera, light, mode words, strips,
+// buffers) are used by that phase only, but as kernel arguments the compiler loads them once, before the loop, and keeps
+// them in scalar registers for the kernel's lifetime -- beside the probe loop's wave masks they do not fit (74 spilled
+// SGPRs: the phase fetched them back from vector-register lanes with ~150 v_readlane + s_nop pairs per execution).  With
+// VXRT_KERNARG_RELOAD the phase reads them from the kernel-argument segment through a pointer the optimiser cannot see
+// through (an empty asm "modifies" it at every execution), so the loads stay inside the phase -- a few s_load_dwordx8/x16
+// from the scalar cache -- and the values occupy scalar registers only while the phase runs.
+// Measured (profiles/r03_kernarg_reload.md): spilled SGPRs 74 -> 0, spilled VGPRs 12 -> 7 (one view: 7 -> 0, no scratch at
+// all), v_readlane in the kernel 150 -> 8; 16 views per launch 5602 -> 5707 Mrays/s (+1.9 %), one view per launch +1.2 %.
+#ifndef VXRT_NO_KERNARG_RELOAD
+#define VXRT_KERNARG_RELOAD 1
+#endif
+__device__ __forceinline__ const RenderArgs& kernarg_reload(const RenderArgs& in_registers)
+{
+#ifdef VXRT_KERNARG_RELOAD
+    auto* p = (const __attribute__((address_space(4))) RenderArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const RenderArgs*)p;
+#else
+    return in_registers;
+#endif
+}
+
+// BOUNCE2: the second-bounce extension (bounce_depth 2) is compiled into its own instantiation -- carried as a
+// run-time branch it cost the reference ray set 29 more spilled VGPRs and 4 % of its speed.
+// MULTI: several views of the world in one launch (vxrt_render_views).  The queue runs through view 0's tiles, then
+// view 1's, ...: the next view's first tiles fill the lanes the previous view's last rays leave, so only the last
+// view of a launch pays the low-occupancy tail.  A lane keeps its pixel's view in the upper half of px_row.
 #ifndef VXRT_PERSIST2_OCC
 #define VXRT_PERSIST2_OCC 5
 #endif
 // Vote thresholds of this kernel (vote_run: a parked phase runs when parked * N >= the other live lanes).  The probes
-// of this tracer cost less than half of WaveTracer's while the phases cost about the same, so waiting for more lanes pays:
+// are cheap beside the phases, so waiting for more lanes pays:
 // end-of-walk waits until its lanes are as many as the others (N = 1), ray-finished and the tight-box phase (which now
 // also enters the brick) until they are half as many.  Sweep in profiles/r03_variant7.md.
-// What runs between the probe pairs of an iteration: 0 = nothing (default: the pairs run back to back, the walking mask
-// carried in scalar registers); A/B: 1 = tight box, then end of walk, on fresh votes (variant 5's schedule); 2 = the tight box only
-#ifndef VXRT_INNER_CASCADE
-#define VXRT_INNER_CASCADE 0
-#endif
 // probe pairs per loop iteration (between two rounds of votes)
 #ifndef VXRT_SUBROUNDS2
 #define VXRT_SUBROUNDS2 3
@@ -423,49 +552,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_next_ticks += wall_clock64();
         }
 
-        // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS groups of VXRT_STEPS_PER_ROUND probes with
-        // the cheap half of the cascade (box, end on fresh votes) between the groups: the ballots and branches of a
-        // vote are paid once per group, box/end lanes wait at most one group, and the expensive ray-finished phase
-        // is voted once per round.  Measured (groups x probes): 1x1 3.53, 1x2 3.96, 1x3 4.02 Grays/s without the
-        // cascade; with it 1x3 4.18, 1x4 4.21, 2x2 4.31, 2x3 and 2x4 the same, 3x3 4.37, 3x2 4.12 (register allocation),
-        // 4x2 falls into scratch.  The same schedule as a rolled loop (vote the ray-finished phase every 2nd or 3rd
-        // round of 2 probes) pays the round's four ballots and the loop branch per group: 4.02.
-#if VXRT_INNER_CASCADE == 0
+        // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS2 probe pairs back to back: the walking mask is
+        // carried from probe to probe in scalar registers, the ballots and branches of a vote are paid once per round
+        // (votes between the pairs only split the phases' lanes: -5 %, profiles/r03_variant7.md)
         T.probe_pairs<VXRT_SUBROUNDS2>(W);
-#else
-        for (int g = 0; g < VXRT_SUBROUNDS2; ++g) {
-            if (g > 0 && VXRT_INNER_CASCADE != 0) {
-                int m_w = __popcll(__ballot(T.st == ST_WALK)), m_b = __popcll(__ballot(T.st == ST_BOX)),
-                    m_e = VXRT_INNER_CASCADE == 2 ? 0 : __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
-                if (vote2(m_b, m_w, VXRT_VOTE2_BOX, VXRT_VOTE2_ABS_BOX)) {
-                    if (STATS) {
-                        dg_runs[2] += 1u;
-                        dg_lanes[2] += (unsigned)m_b;
-                        dg_park_ticks -= wall_clock64();
-                    }
-                    T.phase_box<STATS>(W);
-                    if (STATS)
-                        dg_park_ticks += wall_clock64();
-                    m_b = 0;
-                    if (VXRT_INNER_CASCADE == 1) {
-                        m_w = __popcll(__ballot(T.st == ST_WALK));
-                        m_e = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
-                    }
-                }
-                if (VXRT_INNER_CASCADE == 1 && vote2(m_e, m_w + m_b, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
-                    if (STATS) {
-                        dg_runs[1] += 1u;
-                        dg_lanes[1] += (unsigned)m_e;
-                        dg_park_ticks -= wall_clock64();
-                    }
-                    T.phase_end<STATS>(W);
-                    if (STATS)
-                        dg_park_ticks += wall_clock64();
-                }
-            }
-            T.probe_group(W);
-        }
-#endif
     }
 
     if (lane == 0) {

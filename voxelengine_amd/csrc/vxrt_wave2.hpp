@@ -1,11 +1,21 @@
-// vxrt_wave2.hpp -- the two-level brickmap DDA of vxrt_wave.hpp re-designed for what a gfx950 SIMD actually issues.
+// vxrt_wave2.hpp -- the two-level brickmap DDA (Raytrace / DDARayTraversal, VoxelRT/VolumeRaytracer.cu:176-525) as a flat,
+// wave-level state machine made for what a gfx950 SIMD actually issues.  The one tracer of the product kernels
+// (k_render_persist2, k_trace_batch_persist, k_trace_batch_wave2); trace_direct (vxrt_device.hpp) is the straightforward
+// cross-check.
 //
-// profiles/r03_instr_cost.md: the render kernels are bound by the vector ALU pipe, and its instructions come in two
-// classes -- ~2.3 cycles per wave64 instruction (add / sub / mul f32, and / or / xor, add / sub u32, right shifts, moves,
-// with vector or constant operands) and ~4.15 cycles (every compare, v_cndmask, min / max, conversions, every
-// three-operand form, anything with a scalar-register operand) -- beside a scalar pipe with one instruction per ~4.15
-// cycles.  WaveTracer::step2 is 71 slow + 34 fast vector instructions per probe pair (373 cycles).  This tracer keeps the
-// same results (Raytrace / DDARayTraversal, VoxelRT/VolumeRaytracer.cu:176-525) with a probe made for that machine:
+// Organisation (rounds 1-2, profiles/r01_*, r02_*): ONE loop for 64 rays; every iteration probes one cell and advances
+// one step for every walking lane, on the coarse grid or inside a brick alike.  The rare, expensive events PARK the lane
+// -- the tight-box test of an occupied coarse cell with the entry into its brick (ST_BOX), the end of a walk with the brick
+// exit / ulp nudge / ray end (ST_END, ST_ENDHIT) -- and a __ballot vote runs a parked phase only when enough lanes wait for
+// it.  Per-ray invariants are hoisted (1/(d or eps) of the slab test, |1/d| of the DDA); the 8-byte cell_meta record read
+// for the slab test also carries the brick's pool slot.  The state only the parked phases touch lives in the wave's LDS
+// block, one 64-lane column per field (`cold`), so the probe loop fits 96 VGPRs = 5 waves per SIMD.
+//
+// The probe (round 3, profiles/r03_instr_cost.md): the render kernels are bound by the vector ALU pipe, and its
+// instructions come in two classes -- ~2.3 cycles per wave64 instruction (add / sub / mul f32, and / or / xor, add / sub
+// u32, right shifts, moves, with vector or constant operands) and ~4.15 cycles (every compare, v_cndmask, min / max,
+// conversions, every three-operand form, anything with a scalar-register operand) -- beside a scalar pipe with one
+// instruction per ~4.15 cycles.  Hence:
 //
 //  * The DDA advance is SPECULATIVE and exec-masked.  A DDA's path does not depend on the voxels, only where it stops
 //    does; so every walking lane advances in every probe, before its occupancy word has arrived, and the word only
@@ -28,13 +38,19 @@
 //    recomputes the bit index from the cell): edge-rule starts on several far faces at once, starts whose first crossing
 //    may fail the region check.  The common edge-rule start (one far face, stepped first) costs one subtraction per pair.
 //
-// Limits (tracer2_fits; the launch policy keeps the round-2 kernels otherwise): coarse dimensions x, z <= 1022 and
-// y <= 510 cells (rem's fields), and a walk cannot run into MAX_STEPS (cx + cy + cz + 4 < 2048), so stepsTaken needs no
-// counter.  The world's tables need addressable slack of one x-z slice before and behind the coarse bits and of one
+// Wide grids (W.c_wide, set by the host: a coarse dimension beyond rem's fields -- x, z > 1020 or y > 508 cells -- or a
+// grid a single walk could cross in MAX_STEPS iterations or more, cx + cy + cz + 4 >= 2048).  The probes are the same; a
+// field of rem then holds the steps left to a VIRTUAL face, min(steps to the real face, a cap), and the rest sits in two
+// cold words (CF_OFF_XZ, CF_OFF_Y).  A field that runs out raises its guard as a real face does; the end-of-walk phase
+// sees the offset, counts the step and re-arms the fields (a lane crosses at least cap + 1 cells between two such trips).
+// The caps also keep the sum of the fields below the iterations the walk has left of DDARayTraversal's MAX_STEPS
+// (:234), so the phase that re-arms is also the place where a walk of 2048 counted steps ends as the reference's loop
+// does: no hit, not out of bounds, Raytrace breaks (:508-511).  Narrow grids never execute any of it (a scalar branch).
+// The world's tables need addressable slack of one x-z slice before and behind the coarse bits and of one
 // brick around the pool (vxrt_api.hip allocates it): a lane that has just left the grid issues one more load.
 #pragma once
 
-#include "vxrt_wave.hpp"
+#include "vxrt_device.hpp"
 #ifdef VXRT_HOST_DEBUG
 #include <cstdio>
 #include <cstdlib>
@@ -42,17 +58,42 @@
 
 namespace vxrt {
 
-enum : uint32_t { ST_ENDHIT = 5u };  // walk ended on an occupied voxel / an occupied coarse cell whose tight box was hit
+// lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase; ray finished; no work left;
+// parked for the end-of-walk phase after a brick probe that found an occupied voxel
+enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u, ST_IDLE = 4u, ST_ENDHIT = 5u };
+
+// unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
+__device__ __forceinline__ f3 normal_decode(uint32_t c)
+{
+    float v = (c & 4u) ? -1.0f : 1.0f;
+    uint32_t a = c & 3u;
+    return mk3(a == 1u ? v : 0.0f, a == 2u ? v : 0.0f, a == 3u ? v : 0.0f);
+}
+
+// a parked phase runs when its lanes, times `num`, are at least the other live lanes (or nobody else can move)
+__device__ __forceinline__ bool vote_run(int parked, int others, int num) { return parked > 0 && parked * num >= others; }
+// thresholds of trace_wave2 (one ray per lane: the batch kernel for small batches, the host harness)
+#ifndef VXRT_VOTE_END
+#define VXRT_VOTE_END 2
+#endif
+#ifndef VXRT_VOTE_BOX
+#define VXRT_VOTE_BOX 4
+#endif
+
+// The "cold" part of a lane's ray -- everything only the parked phases, begin_ray and result touch (the probes never do):
+// one 64-lane column per field in the wave's LDS block (conflict-free ds_read / ds_write), no registers between phases.
+// The small ones share a word: CF_RAY_CODES = entry_code (3 bits) | out_code << 3 | ray_hit << 6 | max_steps << 7,
+// CF_BOX_CODES = c_code (3 bits) | nc_axis << 3 (both written by the tight-box phase only).  CF_OFF_XZ / CF_OFF_Y: wide
+// grids only, the steps to the real faces beyond rem's fields (x | z << 16; y).
+enum : int {
+    CF_RAY_CODES = 0, CF_START_X, CF_START_Y, CF_START_Z, CF_LAST_CI, CF_TOTAL,
+    CF_CHX, CF_CHY, CF_CHZ, CF_BOX_CODES, CF_OFF_XZ, CF_OFF_Y, CF_TRACER_FIELDS
+};
 
 constexpr uint32_t kRemDecX = 1u, kRemDecY = 1u << 11, kRemDecZ = 1u << 21;
 constexpr uint32_t kRemGuards = (1u << 10) | (1u << 20) | (1u << 31);
 constexpr float kThrEps = 9.5367431640625e-07f;  // 2^-20: relative margin of the region-check thresholds
 constexpr float kMinFastDir = 9.094947017729282e-13f;  // 2^-40: smallest direction component begin_walk_fast divides by
-
-__host__ __device__ inline bool tracer2_fits(const WorldView& W)
-{
-    return W.cx <= 1022 && W.cz <= 1022 && W.cy <= 510 && W.f <= 32 && W.cx + W.cy + W.cz + 4 < kMaxSteps;
-}
 
 // The machine's min / max as single instructions (fminf / fmaxf compile to the instruction plus one canonicalising
 // v_max_f32 per operand under IEEE rules).  Callers guarantee ordinary operands (no NaN; see slab_fast).
@@ -95,7 +136,7 @@ struct WaveTracer2 {
     uint32_t dn;              // per ray: bit k set where the ray does not move up axis k (d_k <= 0)
     f3 point;                 // HitIntersectedPoint of the walk that ended (tight-box phase / end-of-walk phase)
     lanemask_t fine_m;        // wave mask: lanes walking inside a brick
-    uint32_t* cold;           // &block[lane]; field F of this lane is cold[F * 64] (CF_* of vxrt_wave.hpp)
+    uint32_t* cold;           // &block[lane]; field F of this lane is cold[F * 64]
     // Probe counters of SURVEY 8(d)'s algorithmic bytes (the STATS instantiations of the phases only; dead otherwise):
     // in-range coarse probes (:247-256), brick entries (:420), in-range brick probes (:276).  They fall out of the walk's
     // packed step counters when the walk ends -- a walk that ends after k advances has probed k + 1 cells -- so the probes
@@ -174,7 +215,13 @@ struct WaveTracer2 {
     __device__ __forceinline__ void cells_of(const WorldView& W, bool fine, uint32_t r, int& x, int& y, int& z) const
     {
         const int dmx = fine ? W.f : W.cx, dmy = fine ? W.f : W.cy, dmz = fine ? W.f : W.cz;
-        const int fx = (int)rem_fx(r), fy = (int)rem_fy(r), fz = (int)rem_fz(r);
+        int fx = (int)rem_fx(r), fy = (int)rem_fy(r), fz = (int)rem_fz(r);
+        if (W.c_wide) {  // (wave-uniform) the fields count down to virtual faces: the real ones are further by the offsets
+            const uint32_t oxz = cold[CF_OFF_XZ * 64], oy = cold[CF_OFF_Y * 64];
+            fx += fine ? 0 : (int)(oxz & 0xFFFFu);
+            fy += fine ? 0 : (int)oy;
+            fz += fine ? 0 : (int)(oxz >> 16);
+        }
         x = d.x > 0 ? dmx - 1 - fx : fx;  // (an axis that moves up never starts on its far face: no pad)
         y = d.y > 0 ? dmy - 1 - fy : fy;
         z = d.z > 0 ? dmz - 1 - fz : fz;
@@ -227,11 +274,20 @@ struct WaveTracer2 {
         // inside: up: 0 <= f <= dim - 1; down: 0 <= f <= dim (f == dim only under the edge rule, which it then switches on,
         // :216-232)
         const bool inside = fx < (uint32_t)dmx - nx && fy < (uint32_t)dmy - ny && fz < (uint32_t)dmz - nz && !zero_on_face;
-        rem = rp = rpp = inside ? (fx | (fy << 11) | (fz << 21)) : 0u;
-        rem0 = inside ? fx + fy + fz : 0u;
+        uint32_t px = fx, py = fy, pz = fz;  // what rem's fields are armed with
+        if (!FINE && W.c_wide) {  // (wave-uniform) wide grid: virtual faces, the whole MAX_STEPS budget ahead
+            constexpr uint32_t cap = ((uint32_t)kMaxSteps - 1u) / 3u;
+            px = min(fx, min(cap, kFieldCapXZ));
+            py = min(fy, min(cap, kFieldCapY));
+            pz = min(fz, min(cap, kFieldCapXZ));
+            cold[CF_OFF_XZ * 64] = (fx - px) | ((fz - pz) << 16);
+            cold[CF_OFF_Y * 64] = fy - py;
+        }
+        rem = rp = rpp = inside ? (px | (py << 11) | (pz << 21)) : 0u;
+        rem0 = inside ? px + py + pz : 0u;
         // lookups use the cell clamped to dim-1 (:242-244; differs from the cell only on a far face under the edge rule)
         const int q_x = clamp_cell(c_x, dmx - 1), q_y = clamp_cell(c_y, dmy - 1), q_z = clamp_cell(c_z, dmz - 1);
-        idx = cell_index(q_x, q_y, q_z, (int)row, (int)slice) + slice;
+        idx = cell_index(q_x, q_y, q_z, (int)row, dmz) + slice;
         di_x = nx | 1u;
         di_z = (row ^ nz) - nz;
         di_y = (slice ^ ny) - ny;
@@ -330,7 +386,7 @@ struct WaveTracer2 {
         cells_of(W, is_fine, rem, x, y, z);
         const int dmx = is_fine ? W.f : W.cx, dmy = is_fine ? W.f : W.cy, dmz = is_fine ? W.f : W.cz;
         const int row = is_fine ? W.f_row : W.c_row, slice = is_fine ? W.f_slice : W.c_slice;
-        const uint32_t exact = cell_index(min(x, dmx - 1), min(y, dmy - 1), min(z, dmz - 1), row, slice) + (uint32_t)slice;
+        const uint32_t exact = cell_index(min(x, dmx - 1), min(y, dmy - 1), min(z, dmz - 1), row, dmz) + (uint32_t)slice;
         idx = single ? exact : idx;
         const bool pending = x == dmx || y == dmy || z == dmz;
         t_hi = (single && !pending && lin_inside) ? t_hi_real : t_hi;
@@ -353,7 +409,22 @@ struct WaveTracer2 {
             const bool hit = st == ST_ENDHIT;
             const uint32_t dec_last = rp - rem, dec_prev = rpp - rp;
             const bool stepped = dec_last != 0u;
-            const bool exiting = (rem & kRemGuards) != 0u || !stepped;
+            const bool guard = (rem & kRemGuards) != 0u;
+            bool exiting = guard || !stepped;
+            // wide grids: a guard raised by a field that ran out before its real face (`virt`) is a step to validate and
+            // count like a suspected one, and the walk's MAX_STEPS-th counted step ends it (`exhausted`; :234)
+            bool virt = false, exhausted = false;
+            uint32_t offx = 0u, offy = 0u, offz = 0u;
+            if (W.c_wide) {
+                const uint32_t oxz = cold[CF_OFF_XZ * 64], oy = cold[CF_OFF_Y * 64];
+                offx = oxz & 0xFFFFu;
+                offy = oy;
+                offz = oxz >> 16;
+                const uint32_t off_k = dec_last == kRemDecX ? offx : (dec_last == kRemDecY ? offy : offz);
+                virt = !is_fine && guard && stepped && off_k != 0u;
+                exiting = exiting && !virt;
+                exhausted = virt && !hit && rem0 - rem_sum(rp) + 1u >= (uint32_t)kMaxSteps;
+            }
             const float F = W.ff;
             const f3 lin = mk3(ws.x + (tl * d.x), ws.y + (tl * d.y), ws.z + (tl * d.z));
             int bx, by, bz;
@@ -363,8 +434,26 @@ struct WaveTracer2 {
                               dec_last == kRemDecZ ? (float)(bz + (d.z > 0 ? 1 : 0)) : lin.z);
             const bool region_fail = is_fine && stepped &&
                                      (cr.x < 0.0f || cr.x > F || cr.y < 0.0f || cr.y > F || cr.z < 0.0f || cr.z > F);
-            const bool resume = !hit && !exiting && !region_fail;  // a step that was only suspected: walk on
+            const bool resume = !hit && !exiting && !region_fail && !exhausted;  // a step that was only suspected: walk on
             if (resume) {
+                if (W.c_wide) {
+                    // re-arm the fields of a lane whose virtual face was reached: the steps left to the real faces after this
+                    // step, capped so that their sum stays below the iterations the walk has left; the history in the new frame
+                    const uint32_t so_far = rem0 - rem_sum(rp) + 1u;  // counted steps of this walk, this one included
+                    const uint32_t cap = ((uint32_t)kMaxSteps - so_far - 1u) / 3u;
+                    const uint32_t tx = rem_fx(rp) + offx - (dec_last == kRemDecX ? 1u : 0u), ty = rem_fy(rp) + offy - (dec_last == kRemDecY ? 1u : 0u),
+                                   tz = rem_fz(rp) + offz - (dec_last == kRemDecZ ? 1u : 0u);
+                    const uint32_t px = min(tx, min(cap, kFieldCapXZ)), py = min(ty, min(cap, kFieldCapY)), pz = min(tz, min(cap, kFieldCapXZ));
+                    const uint32_t armed = px | (py << 11) | (pz << 21);
+                    if (virt) {
+                        cold[CF_OFF_XZ * 64] = (tx - px) | ((tz - pz) << 16);
+                        cold[CF_OFF_Y * 64] = ty - py;
+                    }
+                    rem = virt ? armed : rem;
+                    rp = virt ? armed + dec_last : rp;
+                    rpp = virt ? armed + dec_last + dec_prev : rpp;
+                    rem0 = virt ? so_far + px + py + pz : rem0;
+                }
                 const bool lin_inside = !(lin.x < 0.0f || lin.x > F || lin.y < 0.0f || lin.y > F || lin.z < 0.0f || lin.z > F);
                 walk_on(W, is_fine, lin_inside);
                 st = ST_WALK;
@@ -459,7 +548,7 @@ struct WaveTracer2 {
             int x, y, z;
             cells_of(W, false, rp, x, y, z);  // the cell the probe found occupied
             const int qx = min(x, W.cx - 1), qy = min(y, W.cy - 1), qz = min(z, W.cz - 1);
-            const uint32_t ci = cell_index(qx, qy, qz, W.c_row, W.c_slice);
+            const uint32_t ci = cell_index(qx, qy, qz, W.c_row, W.cz);
             const uint2 meta = W.cell_meta[ci];
             const uint32_t e = meta.y;
             const float fqx = (float)qx, fqy = (float)qy, fqz = (float)qz;
@@ -602,7 +691,6 @@ struct WaveTracer2 {
                      : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
 #endif
     }
-    __device__ __forceinline__ void step2(const WorldView& W) { probe_pairs<1>(W); }
 
 #ifndef VXRT_HOST_CHECK
     // One speculative DDA advance (:293-322) of the lanes in `w`, in place.  Outputs (limited to w): sus = lanes whose t
@@ -652,8 +740,6 @@ struct WaveTracer2 {
             : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
     }
 #endif
-
-    __device__ __forceinline__ void probe_group(const WorldView& W) { step2(W); }
 
     // Raytrace's epilogue (:514-523); the ray has ended (st == ST_DONE)
     __device__ __forceinline__ void result(const WorldView& W, TraceResult& out) const

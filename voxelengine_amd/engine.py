@@ -90,7 +90,7 @@ class Context:
         N.check(self._L.vxrt_create(device, C.byref(h)))
         self._h = h
         self.device = device
-        self.kernel_variant = 4  # the library's default (persistent waves, the kernel picked per launch)
+        self.kernel_variant = 4  # the library's default (= 7: persistent wavefronts on the wave-level tracer)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -285,11 +285,8 @@ class Context:
         return st if want_stats else None
 
     def set_kernel_variant(self, variant: int) -> None:
-        """0 = wave-level state machine, 1 = straightforward per-lane loops (A/B, cross-check), 2 = persistent
-        waves with a pixel queue, 3 = persistent waves with the pixel chains pooled in LDS, 5 = persistent waves with the
-        cold state (tracer fields only the parked phases touch, the pixel's chain state) in LDS at 5 waves per SIMD,
-        4 = default: picked per launch -- 5 for multi-view and large single-view launches, 2 for small ones
-        (kernel_for_launch tells which)."""
+        """7 = the product kernels (persistent wavefronts on the wave-level tracer of csrc/vxrt_wave2.hpp), 4 = the default
+        (= 7), 1 = straightforward per-lane loops (cross-check).  kernel_for_launch tells which kernel a launch runs."""
         N.check(self._L.vxrt_set_kernel_variant(self._h, int(variant)))
         self.kernel_variant = int(variant)
 
@@ -298,23 +295,14 @@ class Context:
         grid so that modest batches take the queue kernel."""
         N.check(self._L.vxrt_set_persistent_waves_per_cu(self._h, int(waves_per_cu)))
 
-    def brick_histogram(self) -> np.ndarray:
-        """Experiments build: out[n] = wave-loop iterations (probe-counting launches since the previous read) in which the
-        lanes walking inside a brick sat in n distinct bricks (n = 0..64); out[65 + n]: the same over the iterations with no
-        lane on the coarse grid."""
-        out = np.zeros(130, np.uint64)
-        N.check(self._L.vxrt_debug_brick_histogram(self._h, out.ctypes.data))
-        return out
-
     def has_experiments(self) -> bool:
-        """True for the A/B build of the library (variants 0 and 3, knobs from the environment)."""
+        """True for the A/B build of the library (development knobs read from the environment)."""
         return bool(self._L.vxrt_has_experiments())
 
-    KERNEL_NAMES = {0: "k_render_wave", 1: "k_render", 2: "k_render_persist", 3: "k_render_pool", 5: "k_render_persist_lds",
-                    6: "k_ts_trace", 7: "k_render_persist2"}
+    KERNEL_NAMES = {1: "k_render", 7: "k_render_persist2"}
 
     def kernel_for_launch(self, width: int, height: int, opts: "RenderOptions | None" = None, nviews: int = 0) -> int:
-        """The kernel (0, 1, 2, 3 or 5) a RenderScreen (nviews = 0) or RenderViews launch of this shape runs under the
+        """The kernel (7 or 1) a RenderScreen (nviews = 0) or RenderViews launch of this shape runs under the
         current variant (vxrt_kernel_for_launch); KERNEL_NAMES maps it to the kernel's name in a profile."""
         fl = self._flags(opts, None)
         k = int(self._L.vxrt_kernel_for_launch(self._h, int(width), int(height), C.byref(fl), int(nviews)))
