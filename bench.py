@@ -312,6 +312,44 @@ def run(args):
             s2 = ctx.frame_stats()
             assert s2.total_rays() == rays_local, "ray counts differ between multi-view and two-in-flight launches"
 
+    # SURVEY 8(d)'s side measurements, rank 0 of a one-GPU run only (untimed region): a measured stream-copy ceiling beside the
+    # spec peak -- a device-to-device copy of 1 GiB, bytes read + bytes written per second -- and the per-camera split of the
+    # workload from single-view launches (cameras A-D differ several-fold in rays per pixel chain)
+    copy_gbs = None
+    per_camera = None
+    if rank == 0 and world == 1 and not args.force_gather:
+        nbytes = 1 << 30
+        src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        src.zero_()
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * nbytes * 5 / (e0.elapsed_time(e1) / 1e3) / 1e9
+        del src, dst
+        per_camera = []
+        o = opts()
+        reps = 4
+        for ci, (name, pos, f, u, r) in enumerate(cams):
+            o.frame_number = ci + 1
+            ctx.RenderScreen(W, H, frames[0], pos, f, u, r, o)  # warm
+            torch.cuda.synchronize()
+            ctx.frame_stats()
+            e0.record()
+            for _ in range(reps):
+                ctx.RenderScreen(W, H, frames[0], pos, f, u, r, o)
+            e1.record()
+            torch.cuda.synchronize()
+            sc = ctx.frame_stats()
+            ms = e0.elapsed_time(e1) / reps
+            per_camera.append({"camera": name, "rays": int(sc.total_rays() // reps), "primary_hits": int(sc.primary_hits // reps),
+                               "ms": round(ms, 4), "mrays_s": round(sc.total_rays() / reps / ms / 1e3, 1)})
+
     result = None
     if rank == 0:
         mrays = rays_total / dt / 1e6
@@ -401,6 +439,10 @@ def run(args):
                                    "note": "all ranks on one GPU over gloo: value is not a measurement" if rehearse
                                    else "one-rank NCCL communicator: exercises the N>1 code path, not a scaling number"}
             ctx.frame_stats()
+        if copy_gbs is not None:
+            result["roofline"]["stream_copy_gbs"] = round(copy_gbs, 1)  # measured: 1 GiB device-to-device copy, read + write
+            result["roofline"]["frac_of_stream_copy"] = round(achieved / copy_gbs, 5)
+            result["per_camera_single_view"] = per_camera
         if dt1 is not None:
             result["one_view_per_launch"] = {
                 "value": round(rays_total / dt1 / 1e6, 2), "unit": "Mrays/s",

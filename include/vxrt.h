@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define VXRT_ABI_VERSION 2
+#define VXRT_ABI_VERSION 3
 #define VXRT_EMPTY_SLOT 0xFFFFFFFFu
 #define VXRT_MAX_STEPS 2048 /* MAX_STEPS, VoxelRT/VolumeRaytracer.cuh:235 */
 
@@ -56,6 +56,10 @@ int vxrt_synchronize(vxrt_ctx *ctx);
  * Any other value is refused (rounds 1-3 carried further kernels under 0, 2, 3, 5 and 6; profiles/ keeps their
  * measurements). */
 int vxrt_set_kernel_variant(vxrt_ctx *ctx, int variant);
+/* Test hook of the load guard: on != 0 makes the guard treat the bit tables as if they had been allocated WITHOUT slack
+ * (the real allocations are untouched), so that every slack load counts as stray -- the negative control of the test that
+ * holds guard_stray_loads at zero. */
+int vxrt_debug_guard_pretend_no_slack(vxrt_ctx *ctx, int on);
 /* 1 when the library was built with -DVXRT_EXPERIMENTS (development knobs read from the environment; A/B builds) */
 int vxrt_has_experiments(void);
 /* Size of the persistent kernels' grid, in wavefronts per compute unit at 4 waves per SIMD (default 16 = 4 per SIMD; the
@@ -180,6 +184,11 @@ typedef struct vxrt_frame_stats {
                                phase executions, [5..7] lanes those executions served (same order); persistent kernel
                                only: [8] wave lifetime in 100 MHz ticks, [9] iterations after the tile queue ran dry, [10] ticks inside
                                the ray-finished phase, [11] ticks inside the box and end-of-walk phases */
+    /* Load guard of collect_stats launches (product kernels).  The tracer lets a lane that has just stepped out of a grid
+     * issue one more occupancy load before it stops; the library allocates slack around both bit tables for it.  Counted
+     * per load: beyond a table but inside its allocation (expected, > 0 on ordinary frames), and outside everything
+     * addressable (must be 0: a world path that forgot the slack would show up here, not as a fault in a user's frame). */
+    uint64_t guard_slack_loads, guard_stray_loads;
 } vxrt_frame_stats;
 
 typedef struct vxrt_render_flags {

@@ -24,7 +24,7 @@ def test_every_declared_symbol_is_exported():
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(vx.EXPORTS) == declared
-    assert lib.vxrt_abi_version() == 2
+    assert lib.vxrt_abi_version() == 3
 
 
 def test_host_only_entry_points(vxo):

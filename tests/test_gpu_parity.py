@@ -721,3 +721,65 @@ def test_kernel_for_launch_reports_the_kernel(eng, vxo):
                 ctx.set_kernel_variant(v)
     finally:
         ctx.set_kernel_variant(default)
+
+
+def test_speculative_loads_stay_inside_the_allocators_slack(eng, vxo, tmp_path):
+    """The slack contract of the tracer (csrc/vxrt_wave2.hpp): a lane that has just stepped out of the coarse grid or of a
+    brick issues one more occupancy load before it stops, and every path that makes a world resident (upload, device
+    builder, brickmap file, chunk streaming) goes through the allocator that leaves addressable slack around both bit
+    tables.  The probe-counting kernels classify every load address: frames of the four cameras (sky rays leave through
+    the top face: camera D grazing, B from outside) and a batch with far-face starts and rays leaving through every face
+    must produce loads in the slack (the test does exercise it) and NONE outside what the allocator made addressable.
+    Negative control: with the guard told to pretend the tables have no slack, exactly those loads count as stray -- so a
+    future world path that forgets the slack fails here, not with a fault in a user's frame."""
+    vx, _, torch = eng
+    ctx = vx.Context(0)
+    small = vx.Context(0)
+    small.set_persistent_waves_per_cu(1)   # batches of this size take the queue kernel
+    try:
+        w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)
+        o, d = helpers.mixed_rays(w.dims, 200000, 3)
+        inv = float(np.float32(1.0) / np.sqrt(np.float32(3.0)))
+        path = str(tmp_path / "guard.vxb")
+
+        def exercise(c):
+            slack = stray = 0
+            c.SetEnvironment((inv, inv, inv), (2, 2, 2), (0.5, 0.5, 0.5))
+            c.frame_stats()
+            for cam in "ABCD":
+                pos, f, u, r = helpers.camera(cam, w.dims, vxo)
+                fb = torch.zeros((120, 200, 4), dtype=torch.uint8, device="cuda")
+                c.RenderScreen(200, 120, fb, pos, f, u, r, vx.RenderOptions(shadow=True, bounce_samples=1, frame_number=2,
+                                                                           collect_stats=True))
+                st = c.frame_stats()
+                slack, stray = slack + st.guard_slack_loads, stray + st.guard_stray_loads
+            st = c.Raytrace(o, d, want_stats=True)["stats"]
+            return slack + st.guard_slack_loads, stray + st.guard_stray_loads
+
+        def load_from_file(c):
+            c.load_world(path)
+
+        def stream_from_file(c):
+            c.stream_open(path, 4096)
+            c.stream_focus((128.0, 128.0, 128.0), 1000.0)
+
+        paths = [("upload", lambda c: _upload(c, w)), ("device builder", lambda c: c.build_world(vxo.GEN_INT_TERRAIN, 256, 256, 256, 32)),
+                 ("brickmap file", load_from_file), ("chunk streaming", stream_from_file)]
+        _upload(ctx, w)
+        ctx.save_world(path)
+        for c in (ctx, small):
+            for name, make in paths:
+                make(c)
+                c.guard_pretend_no_slack(False)
+                slack, stray = exercise(c)
+                assert stray == 0, (name, stray)
+                assert slack > 0, name            # the frames and the batch do send lanes one load beyond the tables
+                c.guard_pretend_no_slack(True)
+                slack2, stray2 = exercise(c)
+                assert (slack2, stray2) == (0, slack), name
+                c.guard_pretend_no_slack(False)
+                if name == "chunk streaming":
+                    c.stream_close()
+    finally:
+        ctx.close()
+        small.close()

@@ -3,6 +3,7 @@ wave (tests/tools/hoststub stands in for the few HIP builtins) and run against t
 product's traversal logic -- state machine, parking votes, nudges, the probe counters derived from the packed step
 counters, the wide-grid re-arming of those counters and the MAX_STEPS end of a walk -- on CPU, bit for bit."""
 import os
+import re
 import subprocess
 
 import pytest
@@ -51,7 +52,7 @@ def test_wide_grids_rearm_their_step_counters_and_end_walks_at_max_steps(harness
     enough for one walk to reach DDARayTraversal's MAX_STEPS): results and probe counters equal the oracle's, and the run
     does contain walks that end by exhaustion."""
     out = _run(harness, factor, sx, density, n, sy, sz)
-    exhausted = int(out.split("without a hit")[1].split(")")[0])
+    exhausted = int(re.search(r"without a hit (\d+)", out).group(1))
     if sx // factor >= 2048:
         assert exhausted > 100, out
     _run(harness_small_caps, factor, sx, density, n, sy, sz)

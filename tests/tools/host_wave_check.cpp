@@ -54,7 +54,29 @@ int main(int argc, char** argv)
     W.wmax_x = (float)((double)W.cx - 1e-6); W.wmax_y = (float)((double)W.cy - 1e-6); W.wmax_z = (float)((double)W.cz - 1e-6);
     W.X = S; W.Y = Sy;
     W.c_wide = (force_wide || grid_is_wide(cx, cy, cz)) ? 1 : 0;
+    W.coarse_end = W.coarse_bits + coarse.size(); W.coarse_lo = coarse_pad.data(); W.coarse_hi = coarse_pad.data() + coarse_pad.size();
+    W.pool_end = W.pool + pool.size(); W.pool_lo = pool_pad.data(); W.pool_hi = pool_pad.data() + pool_pad.size();
+    unsigned long long slack_loads = 0, stray_loads = 0;  // load guard: loads beyond a table inside the slack / outside it
     const float ext[3] = {(float)S, (float)Sy, (float)Sz};
+    // a tracer that lives across rays, as a lane of the persistent kernels does (k_render_persist2, k_trace_batch_persist):
+    // whatever a ray leaves behind in the lane's state must not reach the next ray
+    static uint32_t cold_persist[CF_TRACER_FIELDS * 64];
+    WaveTracer2 TP;
+    TP.init(W, cold_persist);
+    auto trace_persistent = [&](const f3 o, const f3 d, TraceResult& out, RayCounters& c) {
+        TP.cnt = RayCounters{0u, 0u, 0u};
+        TP.begin_ray(W, o, d, 2048);
+        TP.after_begin_ray(true);
+        for (;;) {   // the cascade of the persistent kernels: tight box, end of walk, (ray finished), probes
+            if (TP.st == ST_BOX) TP.phase_box<true>(W);
+            if (TP.st == ST_END) TP.phase_end<true>(W);
+            if (ray_over(TP.st)) break;
+            TP.probe_pairs<2, true>(W);
+        }
+        TP.finish_walks<true>(W);
+        TP.result(W, out);
+        c = TP.cnt;
+    };
     int bad = 0, n_hits = 0, n_long = 0, n_exhausted = 0;  // coverage of the run: hits, walks beyond 1024 steps, rays that ran into MAX_STEPS
     for (int i = 0; i < n; ++i) {
         float o[3], d[3];
@@ -82,6 +104,8 @@ int main(int argc, char** argv)
         RayCounters c4{0, 0, 0}, c5{0, 0, 0};
         trace_wave2<1, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
         trace_wave2<3, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
+        TraceResult t6{}; RayCounters c6{0, 0, 0};
+        trace_persistent(mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t6, c6);
         // ... and the straightforward loops the cross-check kernels run
         TraceResult t1{}; RayCounters c1{0, 0, 0};
         trace_direct(W, 2048, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t1, c1);
@@ -91,13 +115,15 @@ int main(int argc, char** argv)
             if (h) ok = ok && memcmp(&t.pos, pp, 12) == 0 && t.normal.x == nn[0] && t.normal.y == nn[1] && t.normal.z == nn[2] && t.vx == vox[0] && t.vy == vox[1] && t.vz == vox[2];
             return ok;
         };
-        const bool ok = same(t4, c4) && same(t5, c5) && same(t1, c1);
+        slack_loads += c4.slack_loads + c5.slack_loads + c6.slack_loads;
+        stray_loads += c4.stray_loads + c5.stray_loads + c6.stray_loads;
+        const bool ok = same(t4, c4) && same(t5, c5) && same(t1, c1) && same(t6, c6) && c4.stray_loads + c5.stray_loads + c6.stray_loads == 0;
         if (!ok && bad++ < 5)
-            printf("ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g) oracle hit=%d steps=%d probes=%llu/%llu/%llu pos (%.9g,%.9g,%.9g) vox (%d,%d,%d) | wave2 hit=%d steps=%d probes=%u/%u/%u pos (%.9g,%.9g,%.9g) vox (%d,%d,%d) | x3 %d | direct %d\n",
+            printf("ray %d o=(%.9g,%.9g,%.9g) d=(%.9g,%.9g,%.9g) oracle hit=%d steps=%d probes=%llu/%llu/%llu pos (%.9g,%.9g,%.9g) vox (%d,%d,%d) | wave2 hit=%d steps=%d probes=%u/%u/%u pos (%.9g,%.9g,%.9g) vox (%d,%d,%d) | x3 %d | direct %d | persistent lane %d: hit=%d steps=%d pos (%.9g,%.9g,%.9g)\n",
                    i, o[0], o[1], o[2], d[0], d[1], d[2], h, steps, (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries,
                    (unsigned long long)st.fine_probes, pp[0], pp[1], pp[2], vox[0], vox[1], vox[2], t4.hit, t4.steps, c4.coarse_probes, c4.brick_entries,
-                   c4.fine_probes, t4.pos.x, t4.pos.y, t4.pos.z, t4.vx, t4.vy, t4.vz, (int)same(t5, c5), (int)same(t1, c1));
+                   c4.fine_probes, t4.pos.x, t4.pos.y, t4.pos.z, t4.vx, t4.vy, t4.vz, (int)same(t5, c5), (int)same(t1, c1), (int)same(t6, c6), t6.hit, t6.steps, t6.pos.x, t6.pos.y, t6.pos.z);
     }
-    printf("mismatches %d of %d  (hits %d, rays of more than 1024 steps %d, of 2048 or more without a hit %d)\n", bad, n, n_hits, n_long, n_exhausted);
+    printf("mismatches %d of %d  (hits %d, rays of more than 1024 steps %d, of 2048 or more without a hit %d; loads in the tables' slack %llu, outside it %llu)\n", bad, n, n_hits, n_long, n_exhausted, slack_loads, stray_loads);
     return bad != 0;
 }

@@ -15,7 +15,7 @@ MODE_SHADED, MODE_DEBUG = 0, 1
 # every symbol include/vxrt.h declares
 EXPORTS = [
     "vxrt_abi_version", "vxrt_create", "vxrt_destroy", "vxrt_last_error", "vxrt_synchronize", "vxrt_set_kernel_variant", "vxrt_kernel_for_launch",
-    "vxrt_has_experiments", "vxrt_set_persistent_waves_per_cu",
+    "vxrt_has_experiments", "vxrt_set_persistent_waves_per_cu", "vxrt_debug_guard_pretend_no_slack",
     "vxrt_upload_world", "vxrt_build_world_procedural", "vxrt_world_info_get", "vxrt_download_world",
     "vxrt_save_world", "vxrt_load_world", "vxrt_world_file_info",
     "vxrt_set_environment", "vxrt_set_fov", "vxrt_set_ortho_window_size", "vxrt_get_directions",
@@ -40,7 +40,8 @@ class WorldInfo(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("primary_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("bounce_rays", C.c_uint64),
                 ("primary_hits", C.c_uint64), ("coarse_probes", C.c_uint64), ("brick_entries", C.c_uint64),
-                ("fine_probes", C.c_uint64), ("dbg", C.c_uint64 * 12)]
+                ("fine_probes", C.c_uint64), ("dbg", C.c_uint64 * 12), ("guard_slack_loads", C.c_uint64),
+                ("guard_stray_loads", C.c_uint64)]
 
     def total_rays(self) -> int:
         return int(self.primary_rays + self.shadow_rays + self.bounce_rays)
@@ -115,6 +116,7 @@ def load() -> C.CDLL:
     L.vxrt_synchronize.argtypes = [C.c_void_p]
     L.vxrt_set_kernel_variant.argtypes = [C.c_void_p, C.c_int]
     L.vxrt_has_experiments.restype = C.c_int
+    L.vxrt_debug_guard_pretend_no_slack.argtypes = [C.c_void_p, C.c_int]
     L.vxrt_set_persistent_waves_per_cu.argtypes = [C.c_void_p, C.c_int]
     L.vxrt_kernel_for_launch.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32]
     L.vxrt_kernel_for_launch.restype = C.c_int

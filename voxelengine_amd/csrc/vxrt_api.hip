@@ -57,6 +57,8 @@ struct vxrt_ctx {
     uint2* d_meta = nullptr;
     uint32_t* d_pool = nullptr;
     uint64_t ncells = 0, nslots = 0, pool_capacity_slots = 0;
+    uint64_t coarse_alloc_bytes = 0, pool_alloc_bytes = 0;  // what is addressable around the two bit tables (load guard)
+    bool guard_no_slack = false;  // vxrt_debug_guard_pretend_no_slack
     // state the reference keeps in globals
     float light_dir[3] = {0, 0, 0};  // g_env is a zero-initialised device global until SetEnvironment (Renderer.cu:89)
     float light_color[3] = {0, 0, 0};
@@ -144,6 +146,13 @@ void fill_view(vxrt_ctx* c, int factor, const int cd[3])
     v.X = cd[0] * factor;
     v.Y = cd[1] * factor;
     v.c_wide = grid_is_wide(cd[0], cd[1], cd[2]) ? 1 : 0;
+    // load guard of the probe-counting kernels: the tables proper, and the allocations around them
+    v.coarse_end = c->d_coarse + (c->ncells + 31) / 32;
+    v.pool_end = c->d_pool + (c->pool_capacity_slots ? c->pool_capacity_slots : 1) * (uint64_t)v.brick_words;
+    v.coarse_lo = c->guard_no_slack ? v.coarse_bits : static_cast<const uint32_t*>(c->coarse_alloc);
+    v.coarse_hi = c->guard_no_slack ? v.coarse_end : v.coarse_lo + c->coarse_alloc_bytes / 4;
+    v.pool_lo = c->guard_no_slack ? v.pool : static_cast<const uint32_t*>(c->pool_alloc);
+    v.pool_hi = c->guard_no_slack ? v.pool_end : v.pool_lo + c->pool_alloc_bytes / 4;
 }
 
 int alloc_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t pool_slots)
@@ -157,11 +166,13 @@ int alloc_world(vxrt_ctx* c, int factor, const int cd[3], uint64_t pool_slots)
     const uint64_t coarse_bytes = ((c->ncells + 31) / 32) * sizeof(uint32_t);
     const uint64_t coarse_slack = (((uint64_t)cd[0] * cd[2] / 8 + 64) + 255) / 256 * 256;
     VX_HIP(hipMalloc(&c->coarse_alloc, coarse_bytes + 2 * coarse_slack));
+    c->coarse_alloc_bytes = coarse_bytes + 2 * coarse_slack;
     c->d_coarse = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->coarse_alloc) + coarse_slack);
     VX_HIP(hipMalloc((void**)&c->d_meta, c->ncells * sizeof(uint2)));
     const uint64_t pool_bytes = (pool_slots ? pool_slots : 1) * bw * sizeof(uint32_t);
     const uint64_t pool_slack = (bw * sizeof(uint32_t) + 255) / 256 * 256;
     VX_HIP(hipMalloc(&c->pool_alloc, pool_bytes + 2 * pool_slack));
+    c->pool_alloc_bytes = pool_bytes + 2 * pool_slack;
     c->d_pool = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(c->pool_alloc) + pool_slack);
     c->pool_capacity_slots = pool_slots;
     return VXRT_OK;
@@ -350,6 +361,18 @@ int vxrt_has_experiments(void)
 #else
     return 0;
 #endif
+}
+
+int vxrt_debug_guard_pretend_no_slack(vxrt_ctx* c, int on)
+{
+    if (!c)
+        return fail(VXRT_ERR_INVALID, "NULL context");
+    c->guard_no_slack = on != 0;
+    if (c->has_world) {
+        const int cd[3] = {c->view.cx, c->view.cy, c->view.cz};
+        vxrt::fill_view(c, c->view.f, cd);
+    }
+    return VXRT_OK;
 }
 
 int vxrt_set_kernel_variant(vxrt_ctx* c, int variant)
@@ -810,6 +833,8 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
     out->dbg[9] = h[vxrt::kStatDbgDrained];
     out->dbg[10] = h[vxrt::kStatDbgNextTicks];
     out->dbg[11] = h[vxrt::kStatDbgParkTicks];
+    out->guard_slack_loads = h[vxrt::kStatGuardSlack];
+    out->guard_stray_loads = h[vxrt::kStatGuardStray];
     return VXRT_OK;
 }
 

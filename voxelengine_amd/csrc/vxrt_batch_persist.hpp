@@ -54,8 +54,8 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
-        const unsigned long long m_next = __ballot(T.st == ST_DONE);
+        const unsigned long long m_end = __ballot(T.st == ST_END);
+        const unsigned long long m_next = __ballot(ray_over(T.st));
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         int c_walk = __popcll(m_walk), c_box = __popcll(m_box), c_end = __popcll(m_end), c_next = __popcll(m_next);
@@ -64,16 +64,17 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             T.phase_box<STATS>(W);
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+            c_end = __popcll(__ballot(T.st == ST_END));
         }
         if (vote_run(c_end, c_walk + c_box, VXRT_BATCH_VOTE_END)) {
             T.phase_end<STATS>(W);
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_next = __popcll(__ballot(T.st == ST_DONE));
+            c_next = __popcll(__ballot(ray_over(T.st)));
         }
         // ---- parked phase: a ray finished -> write its result, take the next ray of the ticket --------------------
         if (vote_run(c_next, c_walk + c_box + c_end, VXRT_BATCH_VOTE_NEXT)) {
+            T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
             bool c_hit = false;
             if (T.st == ST_DONE && my_ray != kNone) {
                 TraceResult t;
@@ -154,13 +155,15 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             n_rays += (uint32_t)__popcll(__ballot(got));
             n_hits += (uint32_t)__popcll(__ballot(c_hit));
         }
-        T.probe_pairs<VXRT_BATCH_PAIRS>(W);
+        T.probe_pairs<VXRT_BATCH_PAIRS, STATS>(W);
     }
 
     if (STATS && B.stats) {
         const unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries),
-                                 p2 = wave_sum(T.cnt.fine_probes);
+                                 p2 = wave_sum(T.cnt.fine_probes), g0 = wave_sum(T.cnt.slack_loads), g1 = wave_sum(T.cnt.stray_loads);
         if (lane == 0) {
+            atomicAdd(&B.stats[kStatGuardSlack], g0);
+            atomicAdd(&B.stats[kStatGuardStray], g1);
             atomicAdd(&B.stats[kStatPrimary], (unsigned long long)n_rays);
             atomicAdd(&B.stats[kStatPrimaryHits], (unsigned long long)n_hits);
             atomicAdd(&B.stats[kStatCoarseProbes], p0);

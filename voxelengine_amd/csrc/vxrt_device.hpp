@@ -56,6 +56,10 @@ struct WorldView {
     float wmax_x, wmax_y, wmax_z;  // (float)((double)c - 1e-6), VolumeRaytracer.cu:375-376
     int X, Y;              // world voxels per axis (hit voxel index)
     int c_wide;            // the coarse grid exceeds WaveTracer2's packed step counters (vxrt_wave2.hpp, "wide grids"): set by the host
+    // Load guard (probe-counting instantiations only; vxrt_wave2.hpp, "slack"): the words of each bit table proper
+    // ([coarse_bits, coarse_end), [pool, pool_end)) and what is addressable around them ([*_lo, *_hi): the allocation).
+    const uint32_t *coarse_end, *coarse_lo, *coarse_hi;
+    const uint32_t *pool_end, *pool_lo, *pool_hi;
 };
 
 // WaveTracer2 (vxrt_wave2.hpp) packs the steps left to the coarse grid's faces into 11 + 10 + 11 bits; a grid beyond that,
@@ -76,6 +80,7 @@ __host__ __device__ inline bool grid_is_wide(int cx, int cy, int cz)
 
 struct RayCounters {
     uint32_t coarse_probes, brick_entries, fine_probes;
+    uint32_t slack_loads = 0, stray_loads = 0;  // load guard: occupancy loads beyond a table but inside its slack / outside everything addressable
 };
 
 // float -> int as the hardware does it (v_cvt_i32_f32): truncation, saturating, NaN -> 0.  Spelled with the

@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
     t.pos = t.normal = mk3(0, 0, 0);
     t.vx = t.vy = t.vz = 0;
     t.ncode = 0u;
-    RayCounters cnt{0u, 0u, 0u};
+    RayCounters cnt{0u, 0u, 0u, 0u, 0u};
     trace_wave2<1, STATS>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63], &cnt);
     if (live) {
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
@@ -377,8 +377,11 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
     }
     if (STATS && B.stats) {
         const unsigned long long r = wave_sum(live ? 1u : 0u), h = wave_sum(live && t.hit ? 1u : 0u), p0 = wave_sum(cnt.coarse_probes),
-                                 p1 = wave_sum(cnt.brick_entries), p2 = wave_sum(cnt.fine_probes);
+                                 p1 = wave_sum(cnt.brick_entries), p2 = wave_sum(cnt.fine_probes), g0 = wave_sum(cnt.slack_loads),
+                                 g1 = wave_sum(cnt.stray_loads);
         if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&B.stats[kStatGuardSlack], g0);
+            atomicAdd(&B.stats[kStatGuardStray], g1);
             atomicAdd(&B.stats[kStatPrimary], r);
             atomicAdd(&B.stats[kStatPrimaryHits], h);
             atomicAdd(&B.stats[kStatCoarseProbes], p0);

@@ -26,6 +26,8 @@ enum StatSlot {
     kStatDbgDrained,    // persistent kernel: iterations after the tile queue ran dry
     kStatDbgNextTicks,  // persistent kernel: 100 MHz ticks inside the ray-finished phase, summed over waves
     kStatDbgParkTicks,  // ... inside the box and end-of-walk phases
+    kStatGuardSlack,    // load guard (probe-counting launches): occupancy loads beyond a table, inside the allocator's slack
+    kStatGuardStray,    // ... and outside everything addressable (must stay 0)
     kStatCount
 };
 

@@ -278,8 +278,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
-        const unsigned long long m_next = __ballot(T.st == ST_DONE);
+        const unsigned long long m_end = __ballot(T.st == ST_END);
+        const unsigned long long m_next = __ballot(ray_over(T.st));
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end), n_next = __popcll(m_next);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_park_ticks += wall_clock64();
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+            c_end = __popcll(__ballot(T.st == ST_END));
         }
         if (vote2(c_end, c_walk + c_box, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
             if (STATS) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_park_ticks += wall_clock64();
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_next = __popcll(__ballot(T.st == ST_DONE));
+            c_next = __popcll(__ballot(ray_over(T.st)));
         }
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
@@ -329,6 +329,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[0] += (unsigned)c_next;
                 dg_next_ticks -= wall_clock64();
             }
+            T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
             const RenderArgs& A = kernarg_reload(A_kern);
             const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
             const f3 L = A.light_dir;
@@ -555,7 +556,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS2 probe pairs back to back: the walking mask is
         // carried from probe to probe in scalar registers, the ballots and branches of a vote are paid once per round
         // (votes between the pairs only split the phases' lanes: -5 %, profiles/r03_variant7.md)
-        T.probe_pairs<VXRT_SUBROUNDS2>(W);
+        T.probe_pairs<VXRT_SUBROUNDS2, STATS>(W);
     }
 
     if (lane == 0) {
@@ -574,10 +575,13 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
     }
     if (STATS) {
         const unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries), p2 = wave_sum(T.cnt.fine_probes);
+        const unsigned long long g0 = wave_sum(T.cnt.slack_loads), g1 = wave_sum(T.cnt.stray_loads);
         if (lane == 0 && A_kern.stats) {
             atomicAdd(&A_kern.stats[kStatCoarseProbes], p0);
             atomicAdd(&A_kern.stats[kStatBrickEntries], p1);
             atomicAdd(&A_kern.stats[kStatFineProbes], p2);
+            atomicAdd(&A_kern.stats[kStatGuardSlack], g0);
+            atomicAdd(&A_kern.stats[kStatGuardStray], g1);
             atomicAdd(&A_kern.stats[kStatDbgIters], dg_iters);
             atomicAdd(&A_kern.stats[kStatDbgWalkLanes], dg_walk);
             atomicAdd(&A_kern.stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);

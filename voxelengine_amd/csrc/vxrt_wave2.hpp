@@ -58,9 +58,12 @@
 
 namespace vxrt {
 
-// lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase; ray finished; no work left;
-// parked for the end-of-walk phase after a brick probe that found an occupied voxel
-enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u, ST_IDLE = 4u, ST_ENDHIT = 5u };
+// Lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase; no work left; and, from ST_DONE
+// upwards, "the ray is over" (ray_over): finished; a brick probe found an occupied voxel (ST_ENDHIT) or the coarse walk
+// stepped out of the world (ST_OUT) -- the two common ends of a ray, which need no end-of-walk phase: the caller's
+// ray-finished phase settles them on its way (finish_walks) and they become ST_DONE.
+enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_IDLE = 3u, ST_DONE = 4u, ST_ENDHIT = 5u, ST_OUT = 6u };
+__device__ __forceinline__ bool ray_over(uint32_t st) { return st >= ST_DONE; }
 
 // unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
 __device__ __forceinline__ f3 normal_decode(uint32_t c)
@@ -171,7 +174,7 @@ struct WaveTracer2 {
         ws = point = mk3(0, 0, 0);
         rem0 = 0u;
         fine_m = 0ull;
-        cnt = RayCounters{0u, 0u, 0u};
+        cnt = RayCounters{0u, 0u, 0u, 0u, 0u};
     }
 
     // slab test against [bmin,bmax] from point s with the hoisted reciprocals (RayIntersectsAABB, :124-174)
@@ -393,20 +396,19 @@ struct WaveTracer2 {
     }
 
     // parked phase: end of a walk (:395-511).  Called by the whole wave (converged); works on the lanes with st == ST_END
-    // (the last advance left the grid and / or was later than t_hi, or the walk never started) and ST_ENDHIT (a brick walk
-    // whose probe found an occupied voxel).  Coarse walks that end on a hit tight box never come here: the tight-box
-    // phase enters the brick itself.
+    // (the last advance left the grid and / or was later than t_hi, or the walk never started).  Coarse walks that end on
+    // a hit tight box never come here (the tight-box phase enters the brick itself), nor do the walks that end a ray in
+    // the two common ways (finish_walks).
     template <bool STATS = false>
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
-        const bool me = st == ST_END || st == ST_ENDHIT;
+        const bool me = st == ST_END;
         const bool is_fine = lane_fine();
         bool go_coarse = false;  // this lane restarts the coarse walk
         if (me) {
-            // ---- what the walk that just ended did.  ST_ENDHIT: the probe of the cell `rp` found it occupied; the advance
-            // after it (rp -> rem) is the reference's exit advance.  ST_END: validate the last advance (rp -> rem, at time
-            // tl) with the reference's expressions.
-            const bool hit = st == ST_ENDHIT;
+            // ---- what the walk that just ended did: validate the last advance (rp -> rem, at time tl) with the
+            // reference's expressions
+            constexpr bool hit = false;  // (walks that end on an occupied voxel are settled by finish_walks)
             const uint32_t dec_last = rp - rem, dec_prev = rpp - rp;
             const bool stepped = dec_last != 0u;
             const bool guard = (rem & kRemGuards) != 0u;
@@ -461,7 +463,6 @@ struct WaveTracer2 {
                 // steps counted by this walk, and its last counted step
                 const bool last_counts = !hit && stepped && !region_fail;
                 const uint32_t steps = rem0 - rem_sum(rp) + (last_counts ? 1u : 0u);
-                const uint32_t dec_c = last_counts ? dec_last : dec_prev;  // the last counted step's axis
                 if (STATS) {
                     // every iteration of the walk up to the cell `rp` was in range and probed its cell (:240-280): the start
                     // cell plus one per advance before rp; a walk that never started (start outside the grid) probed nothing
@@ -478,16 +479,7 @@ struct WaveTracer2 {
                 // ---- Raytrace's loop body after the walk (:395-511)
                 const int total_ = (int)cold[CF_TOTAL * 64] + (int)steps;
                 cold[CF_TOTAL * 64] = (uint32_t)total_;
-                if (hit) {  // :493-506 (brick walks only)
-                    const uint32_t box_codes = cold[CF_BOX_CODES * 64];
-                    const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
-                    // normal code of the hit = (axis + 1) | 4 * negative of the last counted step; the coarse hit's if none
-                    const uint32_t axis1 = dec_c == kRemDecX ? 1u : (dec_c == kRemDecY ? 2u : 3u);
-                    const bool up_last = dec_c == kRemDecX ? d.x > 0 : (dec_c == kRemDecY ? d.y > 0 : d.z > 0);
-                    const uint32_t hit_code = steps == 0u ? (box_codes & 7u) : (axis1 + (up_last ? 0u : 4u));
-                    cold[CF_RAY_CODES * 64] = (ray_codes & ~0x78u) | (hit_code << 3) | 0x40u;
-                    st = ST_DONE;
-                } else if (!is_fine) {
+                if (!is_fine) {
                     st = ST_DONE;  // the coarse walk left the world (:399-401)
                 } else {
                     // brick miss (:431-491): start = hitPosition / f; if start is still inside HitCell, nudge all three
@@ -536,6 +528,43 @@ struct WaveTracer2 {
         }
         // the level mask, where the wave is converged again
         fine_m &= ~__ballot(go_coarse);
+    }
+
+    // The two common ends of a ray, settled where the wave is converged in the caller's ray-finished phase (or after the
+    // loop of trace_wave2) instead of in an end-of-walk phase of their own -- one parked wait and one phase execution less
+    // per ray.  ST_ENDHIT: the brick probe of the cell `rp` found it occupied (:276-280, :493-506); the advance after it
+    // is the reference's exit advance and counts nothing.  ST_OUT: the coarse walk's last advance (rp -> rem) left the
+    // grid; that step is counted, the iteration after it finds the cell out of bounds and Raytrace breaks (:399-401, :508-511).
+    template <bool STATS = false>
+    __device__ __forceinline__ void finish_walks(const WorldView& W)
+    {
+        if (__ballot(st == ST_ENDHIT || st == ST_OUT) == 0ull)
+            return;
+        if (st == ST_ENDHIT) {
+            const uint32_t dec_prev = rpp - rp;  // the last counted step's axis
+            const uint32_t steps = rem0 - rem_sum(rp);
+            const f3 pc = cross_of(W, true, rpp, dec_prev, tp);
+            point.x = steps != 0u ? pc.x : ws.x;
+            point.y = steps != 0u ? pc.y : ws.y;
+            point.z = steps != 0u ? pc.z : ws.z;
+            cold[CF_TOTAL * 64] += steps;
+            const uint32_t box_codes = cold[CF_BOX_CODES * 64];
+            const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
+            // normal code of the hit = (axis + 1) | 4 * negative of the last counted step; the coarse hit's if none
+            const uint32_t axis1 = dec_prev == kRemDecX ? 1u : (dec_prev == kRemDecY ? 2u : 3u);
+            const bool up_last = dec_prev == kRemDecX ? d.x > 0 : (dec_prev == kRemDecY ? d.y > 0 : d.z > 0);
+            const uint32_t hit_code = steps == 0u ? (box_codes & 7u) : (axis1 + (up_last ? 0u : 4u));
+            cold[CF_RAY_CODES * 64] = (ray_codes & ~0x78u) | (hit_code << 3) | 0x40u;
+            if (STATS)
+                cnt.fine_probes += steps + 1u;  // the start cell and one cell per step, the hit cell included
+            st = ST_DONE;
+        } else if (st == ST_OUT) {
+            const uint32_t steps = rem0 - rem_sum(rp) + 1u;
+            cold[CF_TOTAL * 64] += steps;
+            if (STATS)
+                cnt.coarse_probes += steps;  // every cell from the start to `rp`
+            st = ST_DONE;
+        }
     }
 
     // parked phase: tight-box test of an occupied coarse cell (:248-273) and, on a hit, the end of the coarse walk with
@@ -611,16 +640,20 @@ struct WaveTracer2 {
     // t_hi; when the word arrives, see who stood on an occupied cell.  The second probe's address of a pair does not depend
     // on the first word.  The walking mask is carried from probe to probe in scalar registers and `st` is written once,
     // after the last pair; `fix` can only be set by a phase, i.e. before the first pair.
-    template <int PAIRS>
+    // GUARD (the probe-counting instantiations): classify every load address -- inside a table, in the slack the allocator
+    // left around it (a lane that has just left its grid), or outside everything addressable (`stray`: must never happen; it
+    // is what a world path that forgets the slack would produce, and tests/test_gpu_parity.py holds it at zero).
+    template <int PAIRS, bool GUARD = false>
     __device__ __forceinline__ void probe_pairs(const WorldView& W)
     {
-        (void)W;
 #ifdef VXRT_HOST_CHECK
         for (int p = 0; p < 2 * PAIRS; ++p) {
             if (st != ST_WALK)
                 return;
             const uint32_t i1 = idx;
             const uint32_t word = bits[i1 >> 5];
+            if (GUARD)
+                guard_load(W, bits + (i1 >> 5));
             const bool a0 = tn_x < tn_y && tn_x < tn_z;
             const bool a1 = !(tn_x < tn_y) && tn_y < tn_z;
             tp = tl;
@@ -648,18 +681,22 @@ struct WaveTracer2 {
             const bool solid = ((word >> (i1 & 31u)) & 1u) != 0u;
             if (solid)
                 st = lane_fine() ? (uint32_t)ST_ENDHIT : (uint32_t)ST_BOX;
+            else if (gd && !sus && !lane_fine() && !W.c_wide)
+                st = ST_OUT;
             else if (sus || gd)
                 st = ST_END;
         }
 #else
         lanemask_t w = lane_mask(st == ST_WALK);
-        lanemask_t hits = 0ull, other = 0ull;
+        lanemask_t hits = 0ull, other = 0ull, left = 0ull;  // left: the advance left the grid and was not suspected (coarse walks)
 #pragma unroll
         for (int k = 0; k < PAIRS; ++k) {
             lanemask_t sus1, gd1, sus2, gd2;
             // ---- probe 1
             const uint32_t i1 = idx;
             const uint32_t word1 = bits[i1 >> 5];
+            if (GUARD)
+                guard_load(W, bits + (i1 >> 5));
             advance(w, sus1, gd1);
             if (k == 0) {
                 idx -= fix;
@@ -668,6 +705,8 @@ struct WaveTracer2 {
             // ---- probe 2's load
             const uint32_t i2 = idx;
             const uint32_t word2 = bits[i2 >> 5];
+            if (GUARD)
+                guard_load(W, bits + (i2 >> 5));
             // ---- probe 1: who stood on an occupied cell
             const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w;
             const lanemask_t w2 = w & ~(h1 | sus1 | gd1);
@@ -675,9 +714,12 @@ struct WaveTracer2 {
             const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
             hits |= h1 | h2;
             other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
+            left |= (gd1 & ~(sus1 | h1)) | (gd2 & ~(sus2 | h2));
             w = w2 & ~(h2 | sus2 | gd2);
         }
         const lanemask_t park = hits & ~fine_m, lhit = hits & fine_m;
+        // a coarse walk that stepped out of the grid ends the ray (on a wide grid the guard may be a virtual face's: phase_end)
+        const lanemask_t out = W.c_wide ? 0ull : left & ~fine_m;
         unsigned long long save;
         asm volatile("s_mov_b64 %[save], exec\n\t"
                      "s_mov_b64 exec, %[park]\n\t"
@@ -686,10 +728,22 @@ struct WaveTracer2 {
                      "v_mov_b32 %[st], 5\n\t"
                      "s_mov_b64 exec, %[other]\n\t"
                      "v_mov_b32 %[st], 2\n\t"
+                     "s_mov_b64 exec, %[out]\n\t"
+                     "v_mov_b32 %[st], 6\n\t"
                      "s_mov_b64 exec, %[save]"
                      : [st] "+v"(st), [save] "=&s"(save)
-                     : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
+                     : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other), [out] "s"(out));
+        static_assert(ST_BOX == 1u && ST_ENDHIT == 5u && ST_END == 2u && ST_OUT == 6u, "state codes of the asm above");
 #endif
+    }
+
+    __device__ __forceinline__ void guard_load(const WorldView& W, const uint32_t* a)
+    {
+        // (straight-line: a branch here would sit between the probes' wave-mask arithmetic)
+        const uint32_t in_table = (uint32_t)(a >= W.coarse_bits) & (uint32_t)(a < W.coarse_end) | (uint32_t)(a >= W.pool) & (uint32_t)(a < W.pool_end);
+        const uint32_t addressable = (uint32_t)(a >= W.coarse_lo) & (uint32_t)(a < W.coarse_hi) | (uint32_t)(a >= W.pool_lo) & (uint32_t)(a < W.pool_hi);
+        cnt.slack_loads += (in_table ^ 1u) & addressable;
+        cnt.stray_loads += addressable ^ 1u;
     }
 
 #ifndef VXRT_HOST_CHECK
@@ -783,7 +837,7 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        const unsigned long long m_end = __ballot(T.st == ST_END);
         if ((m_walk | m_box | m_end) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
@@ -791,14 +845,17 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
             T.template phase_end<STATS>(W);
         if (vote_run(n_box, n_walk, VXRT_VOTE_BOX))
             T.template phase_box<STATS>(W);
-        T.template probe_pairs<PAIRS>(W);
+        T.template probe_pairs<PAIRS, STATS>(W);
     }
+    T.template finish_walks<STATS>(W);
     if (active)
         T.result(W, out);
     if (STATS && counters) {
         counters->coarse_probes += T.cnt.coarse_probes;
         counters->brick_entries += T.cnt.brick_entries;
         counters->fine_probes += T.cnt.fine_probes;
+        counters->slack_loads += T.cnt.slack_loads;
+        counters->stray_loads += T.cnt.stray_loads;
     }
 }
 

@@ -295,6 +295,11 @@ class Context:
         grid so that modest batches take the queue kernel."""
         N.check(self._L.vxrt_set_persistent_waves_per_cu(self._h, int(waves_per_cu)))
 
+    def guard_pretend_no_slack(self, on: bool) -> None:
+        """Test hook (vxrt_debug_guard_pretend_no_slack): the load guard of collect_stats launches treats the bit tables as
+        allocated without slack."""
+        N.check(self._L.vxrt_debug_guard_pretend_no_slack(self._h, int(bool(on))))
+
     def has_experiments(self) -> bool:
         """True for the A/B build of the library (development knobs read from the environment)."""
         return bool(self._L.vxrt_has_experiments())
