@@ -43,7 +43,12 @@ WORKLOADS = {
     # ablations of configs[2] for kernel work (not bench lines)
     "c3_primary_only": (8192, 512, 8192, 32, 1, 1920, 1080, 0, 0),
     "c3_primary_shadow": (8192, 512, 8192, 32, 1, 1920, 1080, 1, 0),
+    # the reference's SHIPPED configuration: 1024^3 world (VoxelApp/main.cu:24), 1280x720 (:15-16), DEBUG_VIEW + checkerboard
+    # (Renderer.cu:4-5): half the pixels per frame, primary rays only
+    "ref_shipped_720p_checkerboard_debug": (1024, 1024, 1024, 32, 1, 1280, 720, 0, 0),
 }
+# render mode / checkerboard per workload (default: shaded, off)
+WORKLOAD_FLAGS = {"ref_shipped_720p_checkerboard_debug": dict(mode=1, checkerboard=True)}
 
 # Fixed cameras (position as a fraction of the world extent, euler angles for GetDirections); see DESIGN.md.
 CAMERAS = [
@@ -143,6 +148,7 @@ def run(args):
     sharded = world > 1 or args.force_gather
 
     X, Y, Z, F, gen, W, H, shadow, bounce = WORKLOADS[args.workload]
+    wflags = WORKLOAD_FLAGS.get(args.workload, {})
     ctx = vx.Context(local_rank)
     if args.kernel_variant != 4:
         ctx.set_kernel_variant(args.kernel_variant)
@@ -171,7 +177,7 @@ def run(args):
     def opts(stats=False):
         return vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce, bounce_all_hits=bool(args.bounce_all_hits),
                                 bounce_depth=args.bounce_depth, strip_rows=plan.strip_rows, strip_count=world,
-                                strip_index=rank, compact=sharded, collect_stats=stats)
+                                strip_index=rank, compact=sharded, collect_stats=stats, **wflags)
 
     def views_of(i, target, hits=None):
         """the V views of step i, rendered into `target` ((V,H,W,4) frames, or V packed shards back to back)"""
@@ -466,10 +472,10 @@ def run(args):
             # rank 0 only, after the timed regions (the other ranks wait at the closing barrier); N > 1 times a smaller
             # sample so that the whole-node run stays short
             full_opts = lambda: vx.RenderOptions(shadow=bool(shadow), bounce_samples=bounce,  # noqa: E731
-                                                 bounce_all_hits=bool(args.bounce_all_hits), bounce_depth=args.bounce_depth)
+                                                 bounce_all_hits=bool(args.bounce_all_hits), bounce_depth=args.bounce_depth, **wflags)
             nfr = args.cpu_frames if world == 1 else min(args.cpu_frames, V)
             result["cpu_baseline"], result["parity"] = cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of,
-                                                                    full_opts, nfr)
+                                                                    full_opts, nfr, wflags)
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
@@ -488,7 +494,7 @@ def host_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts, cpu_frames):
+def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts, cpu_frames, wflags=None):
     """The CPU oracle (kind "port": this repo's C restatement of the reference algorithm) timed on the GPU box's
     host cores on a bounded sample of the same workload: the frames of `--cpu-frames / V` steps.  The same frames double
     as a parity gate: the HIP framebuffers of the same steps (same launches as the timed ones) must equal the oracle's
@@ -505,14 +511,15 @@ def cpu_baseline(ctx, vx, W, H, shadow, bounce, args, V, frames, views_of, opts,
     hit_mismatch = 0
     nframes = 0
     for s in range(max(1, cpu_frames // V)):
-        frames.zero_()
+        frames.zero_()  # (a checkerboard frame writes half its pixels: both sides start from zeros)
         hits = torch.full((V, H, W), -1, dtype=torch.int64, device=frames.device)
         views = views_of(args.warmup + s, frames, hits)
         ctx.RenderViews(W, H, views, opts())
         gpu_fb, gpu_hit = frames.cpu().numpy(), hits.cpu().numpy()
         for j, v in enumerate(views):
             p = vxo.make_params(W, H, v["origin"], v["fwd"], v["up"], v["right"], frame_number=v["frame_number"], shadow=shadow,
-                                bounce_samples=bounce, bounce_all_hits=args.bounce_all_hits, bounce_depth=args.bounce_depth)
+                                bounce_samples=bounce, bounce_all_hits=args.bounce_all_hits, bounce_depth=args.bounce_depth,
+                                mode=int((wflags or {}).get("mode", 0)), checkerboard=int(bool((wflags or {}).get("checkerboard", False))))
             t0 = time.perf_counter()
             out = world.render(p, fb=np.zeros((H, W, 4), np.uint8), want_hit=True, nthreads=cores)
             secs += time.perf_counter() - t0

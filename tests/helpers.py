@@ -81,3 +81,11 @@ def fibonacci_fan(n, origin):
     d = np.stack([r * np.cos(phi), y, r * np.sin(phi)], 1).astype(np.float32)
     o = np.tile(np.asarray(origin, np.float32), (n, 1))
     return o, d
+
+
+def float_bits(a):
+    """binary32 array -> its bits as uint32, every NaN as the one canonical quiet NaN"""
+    a = np.ascontiguousarray(a, np.float32)
+    b = a.view(np.uint32).copy()
+    b[np.isnan(a)] = 0x7FC00000
+    return b

@@ -65,7 +65,7 @@ while time.time() < t_end:
             if not np.array_equal(g[k_gpu], cpu[k_cpu]):
                 bad = int(np.flatnonzero(g[k_gpu] != cpu[k_cpu])[0])
                 fail("batch %s field %s" % (what, k_gpu), seed, "ray %d o=%r d=%r" % (bad, o[bad], d[bad]))
-        if not np.array_equal(g["hitPoint"].view(np.uint32), cpu["pos"].view(np.uint32)):
+        if not np.array_equal(helpers.float_bits(g["hitPoint"]), helpers.float_bits(cpu["pos"])):
             fail("batch %s" % what, seed, "positions differ")
         if not np.array_equal(g["normal"], cpu["normal"]):
             fail("batch %s" % what, seed, "normals differ")

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END);
-        const unsigned long long m_next = __ballot(ray_over(T.st));
+        const unsigned long long m_end = __ballot(waits_for_end(T.st));
+        const unsigned long long m_next = __ballot(waits_for_next(T.st));
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         int c_walk = __popcll(m_walk), c_box = __popcll(m_box), c_end = __popcll(m_end), c_next = __popcll(m_next);
@@ -64,17 +64,18 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             T.phase_box<STATS>(W);
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(T.st == ST_END));
+            c_end = __popcll(__ballot(waits_for_end(T.st)));
         }
         if (vote_run(c_end, c_walk + c_box, VXRT_BATCH_VOTE_END)) {
             T.phase_end<STATS>(W);
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_next = __popcll(__ballot(ray_over(T.st)));
+            c_next = __popcll(__ballot(waits_for_next(T.st)));
         }
         // ---- parked phase: a ray finished -> write its result, take the next ray of the ticket --------------------
         if (vote_run(c_next, c_walk + c_box + c_end, VXRT_BATCH_VOTE_NEXT)) {
-            T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
+            if (VXRT_FINISH_MODE != 0)
+                T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
             bool c_hit = false;
             if (T.st == ST_DONE && my_ray != kNone) {
                 TraceResult t;

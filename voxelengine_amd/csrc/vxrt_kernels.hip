@@ -405,12 +405,30 @@ int resolve_render_variant(const RenderArgs& A, int variant)
     return variant == 1 ? 1 : 7;
 }
 
-// The persistent grid of a launch.  A full grid is 5 waves per SIMD; launches with few tiles per wave are started with a
-// smaller one, so that every wave still takes several tiles through the queue (its balance) -- see launch_render.
+// The persistent grid of a launch.  A full grid is VXRT_PERSIST2_OCC waves per SIMD: what a large launch wants (latency hiding
+// in steady state).  A small launch ends in a tail in which every resident wave still carries a few pixel chains at low lane
+// utilisation, and that tail's work grows with the number of waves while its length shrinks with the waves per SIMD; so a
+// launch with few tiles per wave of the full grid starts fewer waves, kTilesPerWave tiles of 64 rays each (a tile counts once
+// per ray kind enabled: primary, shadow, bounce), but never fewer than one wave per SIMD while there are four tiles for it.
+// Measured on one MI355X (profiles/r04_grid_policy.md): 1080p primary rays only (32 400 tiles), one view per launch:
+// 5120 / 3840 / 2560 / 1920 / 1280 / 960 waves = 2830 / 3111 / 3481 / 3654 / 3352 / 2948 Mrays/s; 1080p primary + shadow +
+// bounce (97 200 weighted tiles): 5120 / 3840 / 2560 waves = 4626 / 4567 / 4098; 16 views per launch: the full grid.
+constexpr unsigned kTilesPerWave = 17u;
 static unsigned render_grid_waves(const RenderArgs& A, unsigned long long ntiles)
 {
     const unsigned resident = std::max(1u, A.persistent_waves / 4u * (unsigned)VXRT_PERSIST2_OCC);
-    return (unsigned)std::min<unsigned long long>(ntiles, resident);
+    unsigned tiles_per_wave = kTilesPerWave;
+#ifdef VXRT_EXPERIMENTS
+    static const int env_tpw = getenv("VXRT_TILES_PER_WAVE") ? atoi(getenv("VXRT_TILES_PER_WAVE")) : 0;
+    if (env_tpw > 0)
+        tiles_per_wave = (unsigned)env_tpw;
+#endif
+    const unsigned long long kinds = 1ull + (A.mode == 0 && A.shadow ? 1ull : 0ull) + (A.mode == 0 && A.bounce_samples > 0 ? 1ull : 0ull);
+    const unsigned long long weighted = ntiles * kinds;
+    const unsigned long long by_work = (weighted + tiles_per_wave - 1u) / tiles_per_wave;
+    const unsigned long long floor_waves = std::min<unsigned long long>(A.persistent_waves / 4u, (weighted + 3ull) / 4ull);  // one per SIMD
+    const unsigned long long want = std::max(by_work, floor_waves);
+    return (unsigned)std::max<unsigned long long>(1ull, std::min<unsigned long long>(std::min<unsigned long long>(want, resident), ntiles));
 }
 
 hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream_t stream)

@@ -278,8 +278,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END);
-        const unsigned long long m_next = __ballot(ray_over(T.st));
+        const unsigned long long m_end = __ballot(waits_for_end(T.st));
+        const unsigned long long m_next = __ballot(waits_for_next(T.st));
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end), n_next = __popcll(m_next);
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_park_ticks += wall_clock64();
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(T.st == ST_END));
+            c_end = __popcll(__ballot(waits_for_end(T.st)));
         }
         if (vote2(c_end, c_walk + c_box, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
             if (STATS) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_park_ticks += wall_clock64();
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_next = __popcll(__ballot(ray_over(T.st)));
+            c_next = __popcll(__ballot(waits_for_next(T.st)));
         }
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
@@ -329,7 +329,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[0] += (unsigned)c_next;
                 dg_next_ticks -= wall_clock64();
             }
-            T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
+            if (VXRT_FINISH_MODE != 0)
+                T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
             const RenderArgs& A = kernarg_reload(A_kern);
             const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
             const f3 L = A.light_dir;

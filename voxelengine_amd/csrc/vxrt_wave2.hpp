@@ -38,7 +38,7 @@
 //    recomputes the bit index from the cell): edge-rule starts on several far faces at once, starts whose first crossing
 //    may fail the region check.  The common edge-rule start (one far face, stepped first) costs one subtraction per pair.
 //
-// Wide grids (W.c_wide, set by the host: a coarse dimension beyond rem's fields -- x, z > 1020 or y > 508 cells -- or a
+// Wide grids (VXRT_GRID_WIDE(W), set by the host: a coarse dimension beyond rem's fields -- x, z > 1020 or y > 508 cells -- or a
 // grid a single walk could cross in MAX_STEPS iterations or more, cx + cy + cz + 4 >= 2048).  The probes are the same; a
 // field of rem then holds the steps left to a VIRTUAL face, min(steps to the real face, a cap), and the rest sits in two
 // cold words (CF_OFF_XZ, CF_OFF_Y).  A field that runs out raises its guard as a real face does; the end-of-walk phase
@@ -64,6 +64,20 @@ namespace vxrt {
 // ray-finished phase settles them on its way (finish_walks) and they become ST_DONE.
 enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_IDLE = 3u, ST_DONE = 4u, ST_ENDHIT = 5u, ST_OUT = 6u };
 __device__ __forceinline__ bool ray_over(uint32_t st) { return st >= ST_DONE; }
+// Which parked phase the two common ends wait for (votes) and which settles them (finish_walks):
+//   0 = the end-of-walk phase only; 1 = the ray-finished phase only; 2 = they vote with the end-of-walk lanes and are settled
+//   by whichever of the two phases runs first.  Measured in profiles/r04_finish_walks.md.
+// (A/B knob: -DVXRT_NO_WIDE compiles the wide-grid code out, to price it on ordinary grids)
+#ifdef VXRT_NO_WIDE
+#define VXRT_GRID_WIDE(W) false
+#else
+#define VXRT_GRID_WIDE(W) ((W).c_wide)
+#endif
+#ifndef VXRT_FINISH_MODE
+#define VXRT_FINISH_MODE 0
+#endif
+__device__ __forceinline__ bool waits_for_end(uint32_t st) { return VXRT_FINISH_MODE == 1 ? st == ST_END : (st == ST_END || st > ST_DONE); }
+__device__ __forceinline__ bool waits_for_next(uint32_t st) { return VXRT_FINISH_MODE == 1 ? st >= ST_DONE : st == ST_DONE; }
 
 // unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
 __device__ __forceinline__ f3 normal_decode(uint32_t c)
@@ -219,7 +233,7 @@ struct WaveTracer2 {
     {
         const int dmx = fine ? W.f : W.cx, dmy = fine ? W.f : W.cy, dmz = fine ? W.f : W.cz;
         int fx = (int)rem_fx(r), fy = (int)rem_fy(r), fz = (int)rem_fz(r);
-        if (W.c_wide) {  // (wave-uniform) the fields count down to virtual faces: the real ones are further by the offsets
+        if (VXRT_GRID_WIDE(W)) {  // (wave-uniform) the fields count down to virtual faces: the real ones are further by the offsets
             const uint32_t oxz = cold[CF_OFF_XZ * 64], oy = cold[CF_OFF_Y * 64];
             fx += fine ? 0 : (int)(oxz & 0xFFFFu);
             fy += fine ? 0 : (int)oy;
@@ -278,7 +292,7 @@ struct WaveTracer2 {
         // :216-232)
         const bool inside = fx < (uint32_t)dmx - nx && fy < (uint32_t)dmy - ny && fz < (uint32_t)dmz - nz && !zero_on_face;
         uint32_t px = fx, py = fy, pz = fz;  // what rem's fields are armed with
-        if (!FINE && W.c_wide) {  // (wave-uniform) wide grid: virtual faces, the whole MAX_STEPS budget ahead
+        if (!FINE && VXRT_GRID_WIDE(W)) {  // (wave-uniform) wide grid: virtual faces, the whole MAX_STEPS budget ahead
             constexpr uint32_t cap = ((uint32_t)kMaxSteps - 1u) / 3u;
             px = min(fx, min(cap, kFieldCapXZ));
             py = min(fy, min(cap, kFieldCapY));
@@ -402,6 +416,8 @@ struct WaveTracer2 {
     template <bool STATS = false>
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
+        if (VXRT_FINISH_MODE != 1)
+            finish_walks<STATS>(W);
         const bool me = st == ST_END;
         const bool is_fine = lane_fine();
         bool go_coarse = false;  // this lane restarts the coarse walk
@@ -417,7 +433,7 @@ struct WaveTracer2 {
             // count like a suspected one, and the walk's MAX_STEPS-th counted step ends it (`exhausted`; :234)
             bool virt = false, exhausted = false;
             uint32_t offx = 0u, offy = 0u, offz = 0u;
-            if (W.c_wide) {
+            if (VXRT_GRID_WIDE(W)) {
                 const uint32_t oxz = cold[CF_OFF_XZ * 64], oy = cold[CF_OFF_Y * 64];
                 offx = oxz & 0xFFFFu;
                 offy = oy;
@@ -438,7 +454,7 @@ struct WaveTracer2 {
                                      (cr.x < 0.0f || cr.x > F || cr.y < 0.0f || cr.y > F || cr.z < 0.0f || cr.z > F);
             const bool resume = !hit && !exiting && !region_fail && !exhausted;  // a step that was only suspected: walk on
             if (resume) {
-                if (W.c_wide) {
+                if (VXRT_GRID_WIDE(W)) {
                     // re-arm the fields of a lane whose virtual face was reached: the steps left to the real faces after this
                     // step, capped so that their sum stays below the iterations the walk has left; the history in the new frame
                     const uint32_t so_far = rem0 - rem_sum(rp) + 1u;  // counted steps of this walk, this one included
@@ -681,7 +697,7 @@ struct WaveTracer2 {
             const bool solid = ((word >> (i1 & 31u)) & 1u) != 0u;
             if (solid)
                 st = lane_fine() ? (uint32_t)ST_ENDHIT : (uint32_t)ST_BOX;
-            else if (gd && !sus && !lane_fine() && !W.c_wide)
+            else if (gd && !sus && !lane_fine() && !VXRT_GRID_WIDE(W))
                 st = ST_OUT;
             else if (sus || gd)
                 st = ST_END;
@@ -719,7 +735,7 @@ struct WaveTracer2 {
         }
         const lanemask_t park = hits & ~fine_m, lhit = hits & fine_m;
         // a coarse walk that stepped out of the grid ends the ray (on a wide grid the guard may be a virtual face's: phase_end)
-        const lanemask_t out = W.c_wide ? 0ull : left & ~fine_m;
+        const lanemask_t out = VXRT_GRID_WIDE(W) ? 0ull : left & ~fine_m;
         unsigned long long save;
         asm volatile("s_mov_b64 %[save], exec\n\t"
                      "s_mov_b64 exec, %[park]\n\t"
@@ -837,7 +853,7 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END);
+        const unsigned long long m_end = __ballot(waits_for_end(T.st));
         if ((m_walk | m_box | m_end) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
