@@ -259,6 +259,7 @@ def run(args):
                   100.0 * g[2] / it, g[5] / max(g[2], 1), 100.0 * g[3] / it, g[6] / max(g[3], 1), 100.0 * g[10] / max(g[8], 1),
                   100.0 * g[11] / max(g[8], 1)), file=sys.stderr, flush=True)
     bytes_local = sp.algorithmic_bytes()
+    probes_local = (int(sp.coarse_probes), int(sp.brick_entries), int(sp.fine_probes), int(sp.primary_rays))
 
     tot = torch.tensor([float(rays_local), float(bytes_local), float(sum(kernel_ms))], dtype=torch.float64, device=red_dev)
     tmax = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -420,6 +421,9 @@ def run(args):
                          "algorithmic_bytes_per_launch": round(bytes_total / n_launch, 1),
                          "avg_launch_ms": round(avg_kernel_s * 1e3, 4),
                          "bytes_per_ray": round(bytes_total / max(rays_total, 1.0), 1),
+                         # SURVEY 8(d)'s per-ray counters behind the bytes (rank 0's launches): Nc x 28 B + Nb x 24 B + Nf x 4 B + 4 B per pixel
+                         "probes_per_ray": {"coarse_Nc": round(probes_local[0] / max(rays_local, 1), 3), "brick_entries_Nb": round(probes_local[1] / max(rays_local, 1), 3),
+                                            "fine_Nf": round(probes_local[2] / max(rays_local, 1), 3), "pixels": round(probes_local[3] / max(rays_local, 1), 3)},
                          # what the fraction above is and is not: the contract's yardstick is ALGORITHMIC bytes on the
                          # reference's data layout; the bytes that really cross the HBM interface (PMC, profiles/) are a
                          # fraction of them, and the kernel's physical limiter is instruction issue (vector ALU pipe ~93 % busy)

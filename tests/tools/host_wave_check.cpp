@@ -61,21 +61,25 @@ int main(int argc, char** argv)
     // a tracer that lives across rays, as a lane of the persistent kernels does (k_render_persist2, k_trace_batch_persist):
     // whatever a ray leaves behind in the lane's state must not reach the next ray
     static uint32_t cold_persist[CF_TRACER_FIELDS * 64];
-    WaveTracer2 TP;
-    TP.init(W, cold_persist);
-    auto trace_persistent = [&](const f3 o, const f3 d, TraceResult& out, RayCounters& c) {
+    WaveTracerT<false> TPn;
+    WaveTracerT<true> TPw;
+    TPn.init(W, cold_persist);
+    TPw.init(W, cold_persist);
+    auto trace_persistent_on = [&](auto& TP, const f3 o, const f3 d, TraceResult& out, RayCounters& c) {
         TP.cnt = RayCounters{0u, 0u, 0u};
         TP.begin_ray(W, o, d, 2048);
         TP.after_begin_ray(true);
         for (;;) {   // the cascade of the persistent kernels: tight box, end of walk, (ray finished), probes
-            if (TP.st == ST_BOX) TP.phase_box<true>(W);
-            if (TP.st == ST_END) TP.phase_end<true>(W);
-            if (ray_over(TP.st)) break;
-            TP.probe_pairs<2, true>(W);
+            if (TP.st == ST_BOX) TP.template phase_box<true>(W);
+            if (TP.st == ST_END || TP.st == ST_ENDHIT) TP.template phase_end<true>(W);
+            if (TP.st == ST_DONE) break;
+            TP.template probe_pairs<2, true>(W);
         }
-        TP.finish_walks<true>(W);
         TP.result(W, out);
         c = TP.cnt;
+    };
+    auto trace_persistent = [&](const f3 o, const f3 d, TraceResult& out, RayCounters& c) {
+        if (W.c_wide) trace_persistent_on(TPw, o, d, out, c); else trace_persistent_on(TPn, o, d, out, c);
     };
     int bad = 0, n_hits = 0, n_long = 0, n_exhausted = 0;  // coverage of the run: hits, walks beyond 1024 steps, rays that ran into MAX_STEPS
     for (int i = 0; i < n; ++i) {
@@ -102,8 +106,13 @@ int main(int argc, char** argv)
         static uint32_t cold_column[CF_TRACER_FIELDS * 64];
         TraceResult t4{}, t5{};
         RayCounters c4{0, 0, 0}, c5{0, 0, 0};
-        trace_wave2<1, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
-        trace_wave2<3, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
+        if (W.c_wide) {   // (the wide-grid instantiation of the tracer, as the launchers pick it)
+            trace_wave2<1, true, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
+            trace_wave2<3, true, true>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
+        } else {
+            trace_wave2<1, true, false>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t4, cold_column, &c4);
+            trace_wave2<3, true, false>(W, 2048, true, mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t5, cold_column, &c5);
+        }
         TraceResult t6{}; RayCounters c6{0, 0, 0};
         trace_persistent(mk3(o[0], o[1], o[2]), mk3(d[0], d[1], d[2]), t6, c6);
         // ... and the straightforward loops the cross-check kernels run

@@ -35,7 +35,7 @@ constexpr uint32_t kBatchTicket = 64u;  // rays per queue ticket (256 or 1024: 7
 #ifndef VXRT_BATCH_OCC
 #define VXRT_BATCH_OCC 5
 #endif
-template <bool STATS>
+template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(BatchArgs B)
 {
     __shared__ uint32_t cold_block[CF_TRACER_FIELDS * 64];
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
     const int lane = threadIdx.x & 63;
     constexpr unsigned long long kNone = ~0ull;
 
-    WaveTracer2 T;
+    WaveTracerT<WIDE> T;
     T.init(W, &cold_block[lane]);  // st = ST_DONE: every lane starts by asking for a ray
     unsigned long long my_ray = kNone;
     unsigned long long chunk = 0;  // wave-uniform: first ray of the wave's current ticket
@@ -54,28 +54,26 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(waits_for_end(T.st));
-        const unsigned long long m_next = __ballot(waits_for_next(T.st));
+        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        const unsigned long long m_next = __ballot(T.st == ST_DONE);
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         int c_walk = __popcll(m_walk), c_box = __popcll(m_box), c_end = __popcll(m_end), c_next = __popcll(m_next);
         // parked phases as a cascade on fresh votes (see k_render_persist2)
         if (vote_run(c_box, c_walk, VXRT_BATCH_VOTE_BOX)) {
-            T.phase_box<STATS>(W);
+            T.template phase_box<STATS>(W);
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(waits_for_end(T.st)));
+            c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
         }
         if (vote_run(c_end, c_walk + c_box, VXRT_BATCH_VOTE_END)) {
-            T.phase_end<STATS>(W);
+            T.template phase_end<STATS>(W);
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_next = __popcll(__ballot(waits_for_next(T.st)));
+            c_next = __popcll(__ballot(T.st == ST_DONE));
         }
         // ---- parked phase: a ray finished -> write its result, take the next ray of the ticket --------------------
         if (vote_run(c_next, c_walk + c_box + c_end, VXRT_BATCH_VOTE_NEXT)) {
-            if (VXRT_FINISH_MODE != 0)
-                T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
             bool c_hit = false;
             if (T.st == ST_DONE && my_ray != kNone) {
                 TraceResult t;
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             n_rays += (uint32_t)__popcll(__ballot(got));
             n_hits += (uint32_t)__popcll(__ballot(c_hit));
         }
-        T.probe_pairs<VXRT_BATCH_PAIRS, STATS>(W);
+        T.template probe_pairs<VXRT_BATCH_PAIRS, STATS>(W);
     }
 
     if (STATS && B.stats) {

@@ -343,7 +343,7 @@ namespace vxrt {
 
 // The batch query one ray per lane, the tracer's cold fields in LDS: what batches too small for the persistent queue take
 // (BASELINE configs[0]'s million-ray fan: 17.7 Grays/s against 16.6 for the straightforward loops, tools/batch_probe.py).
-template <bool STATS>
+template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
 {
     __shared__ uint32_t cold_block[4][CF_TRACER_FIELDS * 64];
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
     t.vx = t.vy = t.vz = 0;
     t.ncode = 0u;
     RayCounters cnt{0u, 0u, 0u, 0u, 0u};
-    trace_wave2<1, STATS>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63], &cnt);
+    trace_wave2<1, STATS, WIDE>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63], &cnt);
     if (live) {
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
         B.pos[3 * i] = p.x;
@@ -453,7 +453,14 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
         return e;
     const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
     const dim3 g(waves), b(64);
-#define VXRT_LAUNCH_PERSIST(S, B2, M) hipLaunchKernelGGL((k_render_persist2<S, B2, M>), g, b, 0, stream, A)
+    // (ordinary grids and wide ones -- beyond the tracer's packed step counters -- run their own instantiation of the kernel)
+#define VXRT_LAUNCH_PERSIST(S, B2, M)                                                                    \
+    do {                                                                                                 \
+        if (A.W.c_wide)                                                                                  \
+            hipLaunchKernelGGL((k_render_persist2<S, B2, M, true>), g, b, 0, stream, A);                 \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_render_persist2<S, B2, M, false>), g, b, 0, stream, A);                \
+    } while (0)
     if (A.nviews) {
         if (stats && second_bounce) VXRT_LAUNCH_PERSIST(true, true, true);
         else if (stats) VXRT_LAUNCH_PERSIST(true, false, true);
@@ -487,10 +494,14 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
     const unsigned resident = B.persistent_waves / 4u * (unsigned)VXRT_BATCH_OCC;
     const bool persistent = B.ticket && resident && B.n >= 8ull * 64ull * resident;
     if (!persistent) {
-        if (stats)
-            hipLaunchKernelGGL(k_trace_batch_wave2<true>, grid, block, 0, stream, B);
+        if (stats && B.W.c_wide)
+            hipLaunchKernelGGL((k_trace_batch_wave2<true, true>), grid, block, 0, stream, B);
+        else if (stats)
+            hipLaunchKernelGGL((k_trace_batch_wave2<true, false>), grid, block, 0, stream, B);
+        else if (B.W.c_wide)
+            hipLaunchKernelGGL((k_trace_batch_wave2<false, true>), grid, block, 0, stream, B);
         else
-            hipLaunchKernelGGL(k_trace_batch_wave2<false>, grid, block, 0, stream, B);
+            hipLaunchKernelGGL((k_trace_batch_wave2<false, false>), grid, block, 0, stream, B);
         return hipSuccess;
     }
     const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
@@ -498,10 +509,14 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
         return e;
     const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
     const dim3 g((unsigned)(tickets < resident ? tickets : resident)), b(64);
-    if (stats)
-        hipLaunchKernelGGL(k_trace_batch_persist<true>, g, b, 0, stream, B);
+    if (stats && B.W.c_wide)
+        hipLaunchKernelGGL((k_trace_batch_persist<true, true>), g, b, 0, stream, B);
+    else if (stats)
+        hipLaunchKernelGGL((k_trace_batch_persist<true, false>), g, b, 0, stream, B);
+    else if (B.W.c_wide)
+        hipLaunchKernelGGL((k_trace_batch_persist<false, true>), g, b, 0, stream, B);
     else
-        hipLaunchKernelGGL(k_trace_batch_persist<false>, g, b, 0, stream, B);
+        hipLaunchKernelGGL((k_trace_batch_persist<false, false>), g, b, 0, stream, B);
     return hipSuccess;
 }
 

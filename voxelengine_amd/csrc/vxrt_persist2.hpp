@@ -194,7 +194,7 @@ __device__ __forceinline__ bool vote2(int parked, int others, int num, int k)
 #define PX_LD_COL() do { PX_LD_F(PF_COL_X, color.x); PX_LD_F(PF_COL_Y, color.y); PX_LD_F(PF_COL_Z, color.z); } while (0)
 #define PX_ST_COL() do { PX_ST_F(PF_COL_X, color.x); PX_ST_F(PF_COL_Y, color.y); PX_ST_F(PF_COL_Z, color.z); } while (0)
 
-template <bool STATS, bool BOUNCE2, bool MULTI>
+template <bool STATS, bool BOUNCE2, bool MULTI, bool WIDE>
 __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(RenderArgs A_kern)
 {
     constexpr bool LDS = true;  // (the PX_* macros and the tracer's LDS_COLD parameter)
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         return LaneView{A.origin, A.fwd, A.up, A.right, A.frame_number, A.fb, A.color_aov, A.hit_aov};
     };
 
-    WaveTracer2 T;
+    WaveTracerT<WIDE> T;
     T.init(W, &cold_block[lane]);  // st = ST_DONE: every lane starts by asking for a pixel
     uint32_t stage = PX_NONE;
     uint32_t px_tx = 0, px_row = 0;
@@ -278,8 +278,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(waits_for_end(T.st));
-        const unsigned long long m_next = __ballot(waits_for_next(T.st));
+        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        const unsigned long long m_next = __ballot(T.st == ST_DONE);
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end), n_next = __popcll(m_next);
@@ -299,12 +299,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[2] += (unsigned)c_box;
                 dg_park_ticks -= wall_clock64();
             }
-            T.phase_box<STATS>(W);
+            T.template phase_box<STATS>(W);
             if (STATS)
                 dg_park_ticks += wall_clock64();
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(waits_for_end(T.st)));
+            c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
         }
         if (vote2(c_end, c_walk + c_box, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
             if (STATS) {
@@ -312,12 +312,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[1] += (unsigned)c_end;
                 dg_park_ticks -= wall_clock64();
             }
-            T.phase_end<STATS>(W);
+            T.template phase_end<STATS>(W);
             if (STATS)
                 dg_park_ticks += wall_clock64();
             c_end = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_next = __popcll(__ballot(waits_for_next(T.st)));
+            c_next = __popcll(__ballot(T.st == ST_DONE));
         }
         // ---- parked phase: a ray finished -> continue the pixel's chain, store, take the next pixel ------------
         // Every continuation (shadow ray, bounce sample, the next pixel's primary ray) only RECORDS the ray to
@@ -329,8 +329,6 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_lanes[0] += (unsigned)c_next;
                 dg_next_ticks -= wall_clock64();
             }
-            if (VXRT_FINISH_MODE != 0)
-                T.finish_walks<STATS>(W);  // rays that ended on a voxel or left the world: their last walk's results
             const RenderArgs& A = kernarg_reload(A_kern);
             const uint32_t ntx = (A.width + 7u) / 8u, nty = (A.launch_rows + 7u) / 8u, ntiles = ntx * nty;
             const f3 L = A.light_dir;
@@ -557,7 +555,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS2 probe pairs back to back: the walking mask is
         // carried from probe to probe in scalar registers, the ballots and branches of a vote are paid once per round
         // (votes between the pairs only split the phases' lanes: -5 %, profiles/r03_variant7.md)
-        T.probe_pairs<VXRT_SUBROUNDS2, STATS>(W);
+        T.template probe_pairs<VXRT_SUBROUNDS2, STATS>(W);
     }
 
     if (lane == 0) {

@@ -38,14 +38,14 @@
 //    recomputes the bit index from the cell): edge-rule starts on several far faces at once, starts whose first crossing
 //    may fail the region check.  The common edge-rule start (one far face, stepped first) costs one subtraction per pair.
 //
-// Wide grids (VXRT_GRID_WIDE(W), set by the host: a coarse dimension beyond rem's fields -- x, z > 1020 or y > 508 cells -- or a
+// Wide grids (WIDE, set by the host: a coarse dimension beyond rem's fields -- x, z > 1020 or y > 508 cells -- or a
 // grid a single walk could cross in MAX_STEPS iterations or more, cx + cy + cz + 4 >= 2048).  The probes are the same; a
 // field of rem then holds the steps left to a VIRTUAL face, min(steps to the real face, a cap), and the rest sits in two
 // cold words (CF_OFF_XZ, CF_OFF_Y).  A field that runs out raises its guard as a real face does; the end-of-walk phase
 // sees the offset, counts the step and re-arms the fields (a lane crosses at least cap + 1 cells between two such trips).
 // The caps also keep the sum of the fields below the iterations the walk has left of DDARayTraversal's MAX_STEPS
 // (:234), so the phase that re-arms is also the place where a walk of 2048 counted steps ends as the reference's loop
-// does: no hit, not out of bounds, Raytrace breaks (:508-511).  Narrow grids never execute any of it (a scalar branch).
+// does: no hit, not out of bounds, Raytrace breaks (:508-511).  Ordinary grids run the instantiation without any of it.
 // The world's tables need addressable slack of one x-z slice before and behind the coarse bits and of one
 // brick around the pool (vxrt_api.hip allocates it): a lane that has just left the grid issues one more load.
 #pragma once
@@ -58,27 +58,13 @@
 
 namespace vxrt {
 
-// Lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase; no work left; and, from ST_DONE
-// upwards, "the ray is over" (ray_over): finished; a brick probe found an occupied voxel (ST_ENDHIT) or the coarse walk
-// stepped out of the world (ST_OUT) -- the two common ends of a ray, which need no end-of-walk phase: the caller's
-// ray-finished phase settles them on its way (finish_walks) and they become ST_DONE.
-enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_IDLE = 3u, ST_DONE = 4u, ST_ENDHIT = 5u, ST_OUT = 6u };
-__device__ __forceinline__ bool ray_over(uint32_t st) { return st >= ST_DONE; }
-// Which parked phase the two common ends wait for (votes) and which settles them (finish_walks):
-//   0 = the end-of-walk phase only; 1 = the ray-finished phase only; 2 = they vote with the end-of-walk lanes and are settled
-//   by whichever of the two phases runs first.  Measured in profiles/r04_finish_walks.md.
-// (A/B knob: -DVXRT_NO_WIDE compiles the wide-grid code out, to price it on ordinary grids)
-#ifdef VXRT_NO_WIDE
-#define VXRT_GRID_WIDE(W) false
-#else
-#define VXRT_GRID_WIDE(W) ((W).c_wide)
-#endif
-#ifndef VXRT_FINISH_MODE
-#define VXRT_FINISH_MODE 0
-#endif
-__device__ __forceinline__ bool waits_for_end(uint32_t st) { return VXRT_FINISH_MODE == 1 ? st == ST_END : (st == ST_END || st > ST_DONE); }
-__device__ __forceinline__ bool waits_for_next(uint32_t st) { return VXRT_FINISH_MODE == 1 ? st >= ST_DONE : st == ST_DONE; }
-
+// lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase; ray finished; no work left;
+// parked for the end-of-walk phase after a brick probe that found an occupied voxel
+enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u, ST_IDLE = 4u, ST_ENDHIT = 5u };
+// (Measured in round 4 and not kept, profiles/r04_finish_walks.md: the two common ends of a ray -- a brick probe that finds a
+// voxel, a coarse walk that steps out of the world -- settled by the caller's ray-finished phase instead of an end-of-walk
+// phase of their own: 36 % fewer end-of-walk executions, but the finished lanes then idle until the rarer ray-finished phase
+// runs; 16 views per launch 7127 against 7164 Mrays/s.)
 // unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
 __device__ __forceinline__ f3 normal_decode(uint32_t c)
 {
@@ -120,8 +106,9 @@ __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f3
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 #else
-__device__ __forceinline__ float vmin(float a, float b) { return a < b ? a : b; }
-__device__ __forceinline__ float vmax(float a, float b) { return a > b ? a : b; }
+// (host build: IEEE minNum / maxNum as the instructions are -- a NaN operand loses)
+__device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ float vmin3(float a, float b, float c) { return vmin(vmin(a, b), c); }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
 #endif
@@ -131,7 +118,10 @@ __device__ __forceinline__ uint32_t rem_fy(uint32_t r) { return (r >> 11) & 0x3F
 __device__ __forceinline__ uint32_t rem_fz(uint32_t r) { return r >> 21; }
 __device__ __forceinline__ uint32_t rem_sum(uint32_t r) { return rem_fx(r) + rem_fy(r) + rem_fz(r); }
 
-struct WaveTracer2 {
+// WIDE: the instantiation for wide grids (WorldView::c_wide; the launchers pick it): as a run-time branch on every grid its
+// scalar registers and branches cost ordinary grids 1.5 % (profiles/r04_finish_walks.md, `nowide`).
+template <bool WIDE>
+struct WaveTracerT {
     // per ray
     f3 d;
     float ivx, ivy, ivz;  // 1/(d or eps) (:127-129); |iv| is the DDA's tDelta (:199-201)
@@ -223,8 +213,17 @@ struct WaveTracer2 {
         float t_in = vmax3(nx, ny, nz);
         float t_out = vmin3(fx, fy, fz);
         p = mk3(s.x + t_in * d.x, s.y + t_in * d.y, s.z + t_in * d.z);
+#ifdef VXRT_OPT_CODE
+        // the axis code without branches: (axis + 1) | 4 * sign bit of the reciprocal (a reciprocal is never -0 or NaN), then
+        // two selects in the reference's order (:157-171)
+        const uint32_t c1 = ((__float_as_uint(ivx) >> 29) & 4u) | 1u, c2 = ((__float_as_uint(ivy) >> 29) & 4u) | 2u,
+                       c3 = ((__float_as_uint(ivz) >> 29) & 4u) | 3u;
+        const uint32_t c23 = t_in == ny ? c2 : c3;
+        code = t_in == nx ? c1 : c23;
+#else
         code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
                             : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
+#endif
         return !(t_out < vmax(t_in, 0.0f));
     }
 
@@ -233,7 +232,7 @@ struct WaveTracer2 {
     {
         const int dmx = fine ? W.f : W.cx, dmy = fine ? W.f : W.cy, dmz = fine ? W.f : W.cz;
         int fx = (int)rem_fx(r), fy = (int)rem_fy(r), fz = (int)rem_fz(r);
-        if (VXRT_GRID_WIDE(W)) {  // (wave-uniform) the fields count down to virtual faces: the real ones are further by the offsets
+        if (WIDE) {  // (wave-uniform) the fields count down to virtual faces: the real ones are further by the offsets
             const uint32_t oxz = cold[CF_OFF_XZ * 64], oy = cold[CF_OFF_Y * 64];
             fx += fine ? 0 : (int)(oxz & 0xFFFFu);
             fy += fine ? 0 : (int)oy;
@@ -292,7 +291,7 @@ struct WaveTracer2 {
         // :216-232)
         const bool inside = fx < (uint32_t)dmx - nx && fy < (uint32_t)dmy - ny && fz < (uint32_t)dmz - nz && !zero_on_face;
         uint32_t px = fx, py = fy, pz = fz;  // what rem's fields are armed with
-        if (!FINE && VXRT_GRID_WIDE(W)) {  // (wave-uniform) wide grid: virtual faces, the whole MAX_STEPS budget ahead
+        if (!FINE && WIDE) {  // (wave-uniform) wide grid: virtual faces, the whole MAX_STEPS budget ahead
             constexpr uint32_t cap = ((uint32_t)kMaxSteps - 1u) / 3u;
             px = min(fx, min(cap, kFieldCapXZ));
             py = min(fy, min(cap, kFieldCapY));
@@ -410,21 +409,20 @@ struct WaveTracer2 {
     }
 
     // parked phase: end of a walk (:395-511).  Called by the whole wave (converged); works on the lanes with st == ST_END
-    // (the last advance left the grid and / or was later than t_hi, or the walk never started).  Coarse walks that end on
-    // a hit tight box never come here (the tight-box phase enters the brick itself), nor do the walks that end a ray in
-    // the two common ways (finish_walks).
+    // (the last advance left the grid and / or was later than t_hi, or the walk never started) and ST_ENDHIT (a brick walk
+    // whose probe found an occupied voxel).  Coarse walks that end on a hit tight box never come here: the tight-box
+    // phase enters the brick itself.
     template <bool STATS = false>
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
-        if (VXRT_FINISH_MODE != 1)
-            finish_walks<STATS>(W);
-        const bool me = st == ST_END;
+        const bool me = st == ST_END || st == ST_ENDHIT;
         const bool is_fine = lane_fine();
         bool go_coarse = false;  // this lane restarts the coarse walk
         if (me) {
-            // ---- what the walk that just ended did: validate the last advance (rp -> rem, at time tl) with the
-            // reference's expressions
-            constexpr bool hit = false;  // (walks that end on an occupied voxel are settled by finish_walks)
+            // ---- what the walk that just ended did.  ST_ENDHIT: the probe of the cell `rp` found it occupied; the advance
+            // after it (rp -> rem) is the reference's exit advance.  ST_END: validate the last advance (rp -> rem, at time
+            // tl) with the reference's expressions.
+            const bool hit = st == ST_ENDHIT;
             const uint32_t dec_last = rp - rem, dec_prev = rpp - rp;
             const bool stepped = dec_last != 0u;
             const bool guard = (rem & kRemGuards) != 0u;
@@ -433,7 +431,7 @@ struct WaveTracer2 {
             // count like a suspected one, and the walk's MAX_STEPS-th counted step ends it (`exhausted`; :234)
             bool virt = false, exhausted = false;
             uint32_t offx = 0u, offy = 0u, offz = 0u;
-            if (VXRT_GRID_WIDE(W)) {
+            if (WIDE) {
                 const uint32_t oxz = cold[CF_OFF_XZ * 64], oy = cold[CF_OFF_Y * 64];
                 offx = oxz & 0xFFFFu;
                 offy = oy;
@@ -450,11 +448,16 @@ struct WaveTracer2 {
             const f3 cr = mk3(dec_last == kRemDecX ? (float)(bx + (d.x > 0 ? 1 : 0)) : lin.x,
                               dec_last == kRemDecY ? (float)(by + (d.y > 0 ? 1 : 0)) : lin.y,
                               dec_last == kRemDecZ ? (float)(bz + (d.z > 0 ? 1 : 0)) : lin.z);
+#ifdef VXRT_OPT_REGION
+            // (min3 / max3 + two compares: a NaN component loses, and fails none of the reference's six comparisons either)
+            const bool region_fail = is_fine && stepped && ((vmin3(cr.x, cr.y, cr.z) < 0.0f) | (vmax3(cr.x, cr.y, cr.z) > F));
+#else
             const bool region_fail = is_fine && stepped &&
                                      (cr.x < 0.0f || cr.x > F || cr.y < 0.0f || cr.y > F || cr.z < 0.0f || cr.z > F);
+#endif
             const bool resume = !hit && !exiting && !region_fail && !exhausted;  // a step that was only suspected: walk on
             if (resume) {
-                if (VXRT_GRID_WIDE(W)) {
+                if (WIDE) {
                     // re-arm the fields of a lane whose virtual face was reached: the steps left to the real faces after this
                     // step, capped so that their sum stays below the iterations the walk has left; the history in the new frame
                     const uint32_t so_far = rem0 - rem_sum(rp) + 1u;  // counted steps of this walk, this one included
@@ -472,13 +475,18 @@ struct WaveTracer2 {
                     rpp = virt ? armed + dec_last + dec_prev : rpp;
                     rem0 = virt ? so_far + px + py + pz : rem0;
                 }
+#ifdef VXRT_OPT_REGION
+                const bool lin_inside = !((vmin3(lin.x, lin.y, lin.z) < 0.0f) | (vmax3(lin.x, lin.y, lin.z) > F));
+#else
                 const bool lin_inside = !(lin.x < 0.0f || lin.x > F || lin.y < 0.0f || lin.y > F || lin.z < 0.0f || lin.z > F);
+#endif
                 walk_on(W, is_fine, lin_inside);
                 st = ST_WALK;
             } else {
                 // steps counted by this walk, and its last counted step
                 const bool last_counts = !hit && stepped && !region_fail;
                 const uint32_t steps = rem0 - rem_sum(rp) + (last_counts ? 1u : 0u);
+                const uint32_t dec_c = last_counts ? dec_last : dec_prev;  // the last counted step's axis
                 if (STATS) {
                     // every iteration of the walk up to the cell `rp` was in range and probed its cell (:240-280): the start
                     // cell plus one per advance before rp; a walk that never started (start outside the grid) probed nothing
@@ -495,7 +503,16 @@ struct WaveTracer2 {
                 // ---- Raytrace's loop body after the walk (:395-511)
                 const int total_ = (int)cold[CF_TOTAL * 64] + (int)steps;
                 cold[CF_TOTAL * 64] = (uint32_t)total_;
-                if (!is_fine) {
+                if (hit) {  // :493-506 (brick walks only)
+                    const uint32_t box_codes = cold[CF_BOX_CODES * 64];
+                    const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
+                    // normal code of the hit = (axis + 1) | 4 * negative of the last counted step; the coarse hit's if none
+                    const uint32_t axis1 = dec_c == kRemDecX ? 1u : (dec_c == kRemDecY ? 2u : 3u);
+                    const bool up_last = dec_c == kRemDecX ? d.x > 0 : (dec_c == kRemDecY ? d.y > 0 : d.z > 0);
+                    const uint32_t hit_code = steps == 0u ? (box_codes & 7u) : (axis1 + (up_last ? 0u : 4u));
+                    cold[CF_RAY_CODES * 64] = (ray_codes & ~0x78u) | (hit_code << 3) | 0x40u;
+                    st = ST_DONE;
+                } else if (!is_fine) {
                     st = ST_DONE;  // the coarse walk left the world (:399-401)
                 } else {
                     // brick miss (:431-491): start = hitPosition / f; if start is still inside HitCell, nudge all three
@@ -506,7 +523,26 @@ struct WaveTracer2 {
                     float sx = hp.x * W.inv_f, sy = hp.y * W.inv_f, sz = hp.z * W.inv_f;
                     const bool nudge = trunc_equals(sx, fx) & trunc_equals(sy, fy) & trunc_equals(sz, fz);  // :441-444
                     if (__ballot(nudge) != 0ull) {
+#ifdef VXRT_OPT_ULP
+                        // nextafterf of an ordinary value (finite, not zero): the bits +- 1, by the sign of value and direction; the
+                        // general form (zero, infinities, NaN) behind a wave vote
+                        // (direction's sign bit = "towards negative" except for a -0 component: such rays are `special`)
+                        auto ulp_fast = [](float v, float dir) {
+                            const uint32_t b = __float_as_uint(v);
+                            const uint32_t toward_zero = (b ^ __float_as_uint(dir)) >> 31;  // 1: the magnitude shrinks
+                            return __uint_as_float((b + 1u) - (toward_zero + toward_zero));
+                        };
+                        float ux = ulp_fast(sx, d.x), uy = ulp_fast(sy, d.y), uz = ulp_fast(sz, d.z);
+                        const uint32_t m_or = (__float_as_uint(sx) & 0x7FFFFFFFu) - 1u | (__float_as_uint(sy) & 0x7FFFFFFFu) - 1u |
+                                              (__float_as_uint(sz) & 0x7FFFFFFFu) - 1u;  // >= 0x7F7FFFFF: a zero (wraps), an infinity or a NaN
+                        if (__ballot(m_or >= 0x7F7FFFFFu || special) != 0ull) {
+                            ux = ulp_step(sx, d.x < 0);
+                            uy = ulp_step(sy, d.y < 0);
+                            uz = ulp_step(sz, d.z < 0);
+                        }
+#else
                         const float ux = ulp_step(sx, d.x < 0), uy = ulp_step(sy, d.y < 0), uz = ulp_step(sz, d.z < 0);
+#endif
                         sx = nudge ? ux : sx;
                         sy = nudge ? uy : sy;
                         sz = nudge ? uz : sz;
@@ -544,43 +580,6 @@ struct WaveTracer2 {
         }
         // the level mask, where the wave is converged again
         fine_m &= ~__ballot(go_coarse);
-    }
-
-    // The two common ends of a ray, settled where the wave is converged in the caller's ray-finished phase (or after the
-    // loop of trace_wave2) instead of in an end-of-walk phase of their own -- one parked wait and one phase execution less
-    // per ray.  ST_ENDHIT: the brick probe of the cell `rp` found it occupied (:276-280, :493-506); the advance after it
-    // is the reference's exit advance and counts nothing.  ST_OUT: the coarse walk's last advance (rp -> rem) left the
-    // grid; that step is counted, the iteration after it finds the cell out of bounds and Raytrace breaks (:399-401, :508-511).
-    template <bool STATS = false>
-    __device__ __forceinline__ void finish_walks(const WorldView& W)
-    {
-        if (__ballot(st == ST_ENDHIT || st == ST_OUT) == 0ull)
-            return;
-        if (st == ST_ENDHIT) {
-            const uint32_t dec_prev = rpp - rp;  // the last counted step's axis
-            const uint32_t steps = rem0 - rem_sum(rp);
-            const f3 pc = cross_of(W, true, rpp, dec_prev, tp);
-            point.x = steps != 0u ? pc.x : ws.x;
-            point.y = steps != 0u ? pc.y : ws.y;
-            point.z = steps != 0u ? pc.z : ws.z;
-            cold[CF_TOTAL * 64] += steps;
-            const uint32_t box_codes = cold[CF_BOX_CODES * 64];
-            const uint32_t ray_codes = cold[CF_RAY_CODES * 64];
-            // normal code of the hit = (axis + 1) | 4 * negative of the last counted step; the coarse hit's if none
-            const uint32_t axis1 = dec_prev == kRemDecX ? 1u : (dec_prev == kRemDecY ? 2u : 3u);
-            const bool up_last = dec_prev == kRemDecX ? d.x > 0 : (dec_prev == kRemDecY ? d.y > 0 : d.z > 0);
-            const uint32_t hit_code = steps == 0u ? (box_codes & 7u) : (axis1 + (up_last ? 0u : 4u));
-            cold[CF_RAY_CODES * 64] = (ray_codes & ~0x78u) | (hit_code << 3) | 0x40u;
-            if (STATS)
-                cnt.fine_probes += steps + 1u;  // the start cell and one cell per step, the hit cell included
-            st = ST_DONE;
-        } else if (st == ST_OUT) {
-            const uint32_t steps = rem0 - rem_sum(rp) + 1u;
-            cold[CF_TOTAL * 64] += steps;
-            if (STATS)
-                cnt.coarse_probes += steps;  // every cell from the start to `rp`
-            st = ST_DONE;
-        }
     }
 
     // parked phase: tight-box test of an occupied coarse cell (:248-273) and, on a hit, the end of the coarse walk with
@@ -697,14 +696,12 @@ struct WaveTracer2 {
             const bool solid = ((word >> (i1 & 31u)) & 1u) != 0u;
             if (solid)
                 st = lane_fine() ? (uint32_t)ST_ENDHIT : (uint32_t)ST_BOX;
-            else if (gd && !sus && !lane_fine() && !VXRT_GRID_WIDE(W))
-                st = ST_OUT;
             else if (sus || gd)
                 st = ST_END;
         }
 #else
         lanemask_t w = lane_mask(st == ST_WALK);
-        lanemask_t hits = 0ull, other = 0ull, left = 0ull;  // left: the advance left the grid and was not suspected (coarse walks)
+        lanemask_t hits = 0ull, other = 0ull;
 #pragma unroll
         for (int k = 0; k < PAIRS; ++k) {
             lanemask_t sus1, gd1, sus2, gd2;
@@ -730,12 +727,9 @@ struct WaveTracer2 {
             const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
             hits |= h1 | h2;
             other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
-            left |= (gd1 & ~(sus1 | h1)) | (gd2 & ~(sus2 | h2));
             w = w2 & ~(h2 | sus2 | gd2);
         }
         const lanemask_t park = hits & ~fine_m, lhit = hits & fine_m;
-        // a coarse walk that stepped out of the grid ends the ray (on a wide grid the guard may be a virtual face's: phase_end)
-        const lanemask_t out = VXRT_GRID_WIDE(W) ? 0ull : left & ~fine_m;
         unsigned long long save;
         asm volatile("s_mov_b64 %[save], exec\n\t"
                      "s_mov_b64 exec, %[park]\n\t"
@@ -744,12 +738,10 @@ struct WaveTracer2 {
                      "v_mov_b32 %[st], 5\n\t"
                      "s_mov_b64 exec, %[other]\n\t"
                      "v_mov_b32 %[st], 2\n\t"
-                     "s_mov_b64 exec, %[out]\n\t"
-                     "v_mov_b32 %[st], 6\n\t"
                      "s_mov_b64 exec, %[save]"
                      : [st] "+v"(st), [save] "=&s"(save)
-                     : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other), [out] "s"(out));
-        static_assert(ST_BOX == 1u && ST_ENDHIT == 5u && ST_END == 2u && ST_OUT == 6u, "state codes of the asm above");
+                     : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
+        static_assert(ST_BOX == 1u && ST_ENDHIT == 5u && ST_END == 2u, "state codes of the asm above");
 #endif
     }
 
@@ -841,11 +833,11 @@ struct WaveTracer2 {
 };
 
 // one ray per lane, entered by the whole wave at a converged point (host check and the batch test kernel)
-template <int PAIRS = 1, bool STATS = false>
+template <int PAIRS = 1, bool STATS = false, bool WIDE = false>
 __device__ inline void trace_wave2(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
                                    TraceResult& out, uint32_t* cold_column, RayCounters* counters = nullptr)
 {
-    WaveTracer2 T;
+    WaveTracerT<WIDE> T;
     T.init(W, cold_column);
     if (active)
         T.begin_ray(W, origin, ray, max_steps);
@@ -853,7 +845,7 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(waits_for_end(T.st));
+        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
         if ((m_walk | m_box | m_end) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
@@ -863,7 +855,6 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
             T.template phase_box<STATS>(W);
         T.template probe_pairs<PAIRS, STATS>(W);
     }
-    T.template finish_walks<STATS>(W);
     if (active)
         T.result(W, out);
     if (STATS && counters) {
