@@ -27,6 +27,10 @@ namespace vxrt {
 #ifndef VXRT_BATCH_VOTE_BOX
 #define VXRT_BATCH_VOTE_BOX 2
 #endif
+// only walking lanes load (probe_pairs' MASKED)
+#ifndef VXRT_BATCH_MASKED
+#define VXRT_BATCH_MASKED 1
+#endif
 #ifndef VXRT_BATCH_PAIRS
 #define VXRT_BATCH_PAIRS 2
 #endif
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             n_rays += (uint32_t)__popcll(__ballot(got));
             n_hits += (uint32_t)__popcll(__ballot(c_hit));
         }
-        T.template probe_pairs<VXRT_BATCH_PAIRS, STATS>(W);
+        T.template probe_pairs<VXRT_BATCH_PAIRS, STATS, VXRT_BATCH_MASKED != 0>(W);
     }
 
     if (STATS && B.stats) {

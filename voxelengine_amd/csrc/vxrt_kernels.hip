@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
     t.vx = t.vy = t.vz = 0;
     t.ncode = 0u;
     RayCounters cnt{0u, 0u, 0u, 0u, 0u};
-    trace_wave2<1, STATS, WIDE>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63], &cnt);
+    trace_wave2<1, STATS, WIDE, true>(B.W, B.max_steps, live && ray_valid(o, d), o, d, t, &cold_block[threadIdx.x >> 6][threadIdx.x & 63], &cnt);
     if (live) {
         f3 p = t.hit ? t.pos : mk3(kInf, kInf, kInf);
         B.pos[3 * i] = p.x;

@@ -213,17 +213,12 @@ struct WaveTracerT {
         float t_in = vmax3(nx, ny, nz);
         float t_out = vmin3(fx, fy, fz);
         p = mk3(s.x + t_in * d.x, s.y + t_in * d.y, s.z + t_in * d.z);
-#ifdef VXRT_OPT_CODE
         // the axis code without branches: (axis + 1) | 4 * sign bit of the reciprocal (a reciprocal is never -0 or NaN), then
         // two selects in the reference's order (:157-171)
         const uint32_t c1 = ((__float_as_uint(ivx) >> 29) & 4u) | 1u, c2 = ((__float_as_uint(ivy) >> 29) & 4u) | 2u,
                        c3 = ((__float_as_uint(ivz) >> 29) & 4u) | 3u;
         const uint32_t c23 = t_in == ny ? c2 : c3;
         code = t_in == nx ? c1 : c23;
-#else
-        code = (t_in == nx) ? (1u | (ivx < 0.0f ? 4u : 0u))
-                            : (t_in == ny) ? (2u | (ivy < 0.0f ? 4u : 0u)) : (3u | (ivz < 0.0f ? 4u : 0u));
-#endif
         return !(t_out < vmax(t_in, 0.0f));
     }
 
@@ -448,13 +443,8 @@ struct WaveTracerT {
             const f3 cr = mk3(dec_last == kRemDecX ? (float)(bx + (d.x > 0 ? 1 : 0)) : lin.x,
                               dec_last == kRemDecY ? (float)(by + (d.y > 0 ? 1 : 0)) : lin.y,
                               dec_last == kRemDecZ ? (float)(bz + (d.z > 0 ? 1 : 0)) : lin.z);
-#ifdef VXRT_OPT_REGION
-            // (min3 / max3 + two compares: a NaN component loses, and fails none of the reference's six comparisons either)
-            const bool region_fail = is_fine && stepped && ((vmin3(cr.x, cr.y, cr.z) < 0.0f) | (vmax3(cr.x, cr.y, cr.z) > F));
-#else
             const bool region_fail = is_fine && stepped &&
                                      (cr.x < 0.0f || cr.x > F || cr.y < 0.0f || cr.y > F || cr.z < 0.0f || cr.z > F);
-#endif
             const bool resume = !hit && !exiting && !region_fail && !exhausted;  // a step that was only suspected: walk on
             if (resume) {
                 if (WIDE) {
@@ -475,11 +465,7 @@ struct WaveTracerT {
                     rpp = virt ? armed + dec_last + dec_prev : rpp;
                     rem0 = virt ? so_far + px + py + pz : rem0;
                 }
-#ifdef VXRT_OPT_REGION
-                const bool lin_inside = !((vmin3(lin.x, lin.y, lin.z) < 0.0f) | (vmax3(lin.x, lin.y, lin.z) > F));
-#else
                 const bool lin_inside = !(lin.x < 0.0f || lin.x > F || lin.y < 0.0f || lin.y > F || lin.z < 0.0f || lin.z > F);
-#endif
                 walk_on(W, is_fine, lin_inside);
                 st = ST_WALK;
             } else {
@@ -523,7 +509,6 @@ struct WaveTracerT {
                     float sx = hp.x * W.inv_f, sy = hp.y * W.inv_f, sz = hp.z * W.inv_f;
                     const bool nudge = trunc_equals(sx, fx) & trunc_equals(sy, fy) & trunc_equals(sz, fz);  // :441-444
                     if (__ballot(nudge) != 0ull) {
-#ifdef VXRT_OPT_ULP
                         // nextafterf of an ordinary value (finite, not zero): the bits +- 1, by the sign of value and direction; the
                         // general form (zero, infinities, NaN) behind a wave vote
                         // (direction's sign bit = "towards negative" except for a -0 component: such rays are `special`)
@@ -540,9 +525,6 @@ struct WaveTracerT {
                             uy = ulp_step(sy, d.y < 0);
                             uz = ulp_step(sz, d.z < 0);
                         }
-#else
-                        const float ux = ulp_step(sx, d.x < 0), uy = ulp_step(sy, d.y < 0), uz = ulp_step(sz, d.z < 0);
-#endif
                         sx = nudge ? ux : sx;
                         sy = nudge ? uy : sy;
                         sz = nudge ? uz : sz;
@@ -658,7 +640,12 @@ struct WaveTracerT {
     // GUARD (the probe-counting instantiations): classify every load address -- inside a table, in the slack the allocator
     // left around it (a lane that has just left its grid), or outside everything addressable (`stray`: must never happen; it
     // is what a world path that forgets the slack would produce, and tests/test_gpu_parity.py holds it at zero).
-    template <int PAIRS, bool GUARD = false>
+    // MASKED (the batch kernels): only walking lanes load their cell's word; the others load one fixed, hot word (the first
+    // word of the coarse bits: one request per wave, always in cache) whose value is ignored -- an address select, not a branch
+    // (a branch here would sit between the probes' wave-mask arithmetic).  The render kernels' parked lanes re-load the word
+    // of their last probe, which their wave's coherent neighbours keep in cache; a batch has no coherence to rely on, and a
+    // parked lane's load is a miss that competes with the walking lanes' (4 M incoherent rays: profiles/r04_batch_api.md).
+    template <int PAIRS, bool GUARD = false, bool MASKED = false>
     __device__ __forceinline__ void probe_pairs(const WorldView& W)
     {
 #ifdef VXRT_HOST_CHECK
@@ -707,19 +694,27 @@ struct WaveTracerT {
             lanemask_t sus1, gd1, sus2, gd2;
             // ---- probe 1
             const uint32_t i1 = idx;
-            const uint32_t word1 = bits[i1 >> 5];
+            const uint32_t* a1 = bits + (i1 >> 5);
+            if (MASKED)
+                a1 = lane_test(w) ? a1 : W.coarse_bits;
+            const uint32_t word1 = *a1;
             if (GUARD)
-                guard_load(W, bits + (i1 >> 5));
+                guard_load(W, a1);
             advance(w, sus1, gd1);
             if (k == 0) {
                 idx -= fix;
                 fix = 0u;
             }
             // ---- probe 2's load
+            // (probe 2's load is issued before probe 1's word is known: MASKED limits it to the lanes that were walking into
+            // the pair; a lane that stops in probe 1 still loads once more, inside the tables' slack at worst)
             const uint32_t i2 = idx;
-            const uint32_t word2 = bits[i2 >> 5];
+            const uint32_t* a2 = bits + (i2 >> 5);
+            if (MASKED)
+                a2 = lane_test(w) ? a2 : W.coarse_bits;
+            const uint32_t word2 = *a2;
             if (GUARD)
-                guard_load(W, bits + (i2 >> 5));
+                guard_load(W, a2);
             // ---- probe 1: who stood on an occupied cell
             const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w;
             const lanemask_t w2 = w & ~(h1 | sus1 | gd1);
@@ -833,7 +828,7 @@ struct WaveTracerT {
 };
 
 // one ray per lane, entered by the whole wave at a converged point (host check and the batch test kernel)
-template <int PAIRS = 1, bool STATS = false, bool WIDE = false>
+template <int PAIRS = 1, bool STATS = false, bool WIDE = false, bool MASKED = false>
 __device__ inline void trace_wave2(const WorldView& W, const int max_steps, const bool active, const f3 origin, const f3 ray,
                                    TraceResult& out, uint32_t* cold_column, RayCounters* counters = nullptr)
 {
@@ -853,7 +848,7 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
             T.template phase_end<STATS>(W);
         if (vote_run(n_box, n_walk, VXRT_VOTE_BOX))
             T.template phase_box<STATS>(W);
-        T.template probe_pairs<PAIRS, STATS>(W);
+        T.template probe_pairs<PAIRS, STATS, MASKED>(W);
     }
     if (active)
         T.result(W, out);
