@@ -16,8 +16,10 @@
 
 namespace vxrt {
 
-// vote thresholds and probe pairs per round of this kernel (a batch has no coherence: memory latency, not instruction
-// issue, is what its waves wait for, so it votes as the render kernel does and keeps as many loads in flight)
+// Vote thresholds, probe pairs per round and waves per SIMD of this kernel, from profiles/r04_batch_api.md (4 M incoherent
+// rays through the 8192x512x8192 world): a batch has no coherence, memory latency is what its waves wait for -- one probe
+// pair per round (a lane whose walk ended does not wait through two more pairs for its phase), four waves per SIMD (a fifth
+// only adds misses), the render kernel's votes (more eager and more patient ones both lose)
 #ifndef VXRT_BATCH_VOTE_NEXT
 #define VXRT_BATCH_VOTE_NEXT 2
 #endif
@@ -32,12 +34,12 @@ namespace vxrt {
 #define VXRT_BATCH_MASKED 1
 #endif
 #ifndef VXRT_BATCH_PAIRS
-#define VXRT_BATCH_PAIRS 2
+#define VXRT_BATCH_PAIRS 1
 #endif
 constexpr uint32_t kBatchTicket = 64u;  // rays per queue ticket (256 or 1024: 7 % slower on incoherent rays, no faster on short ones)
 
 #ifndef VXRT_BATCH_OCC
-#define VXRT_BATCH_OCC 5
+#define VXRT_BATCH_OCC 4
 #endif
 template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(BatchArgs B)
