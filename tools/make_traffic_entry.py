@@ -3,7 +3,7 @@
 usage: make_traffic_entry.py <tools/prof.sh output dir> <workload> <views per launch> <kernel symbol> <profile tag>
 
 Reads <dir>/summary.txt (tools/prof_summary.py: per-kernel means of the PMC passes), takes the block of <kernel symbol>
-(e.g. "k_render_persist_lds<false, false, true>"), and stores next to the counters the source hash of the library the
+(e.g. "k_render_persist2<false, false, true, false>"), and stores next to the counters the source hash of the library the
 profile was taken with (voxelengine_amd/csrc/libvxrt.so.srchash): bench.py emits the entry's numbers only when both the
 kernel it launches and the library it loaded match, else null and "stale_profile": true.
 """

@@ -33,7 +33,7 @@ for d in sorted(glob.glob(os.path.join(out, "pmc_*"))):
         per_dispatch = collections.defaultdict(float)
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "")
-            if "k_render" not in k and "k_ts_" not in k:
+            if "k_render" not in k:
                 continue
             per_dispatch[(short(k), row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
         for (k, did, cn), v in per_dispatch.items():
