@@ -372,8 +372,10 @@ def run(args):
         issue = None
         stale_profile = None
         kernel_id = ctx.kernel_for_launch(W, H, opts(), V if V > 1 else 0)
-        kernel_symbol = "%s<false,%s,%s>" % (ctx.KERNEL_NAMES[kernel_id], "true" if args.bounce_depth == 2 else "false",
-                                             "true" if V > 1 else "false")
+        # template arguments: <probe counting, second bounce, multi-view, wide grid (beyond the tracer's packed step counters)>
+        wide = vx.grid_is_wide(info.cdims)
+        kernel_symbol = "%s<false,%s,%s,%s>" % (ctx.KERNEL_NAMES[kernel_id], "true" if args.bounce_depth == 2 else "false",
+                                                "true" if V > 1 else "false", "true" if wide else "false")
         if kernel_id == 1:
             kernel_symbol = "k_render<false>"
         # the counting pass above ran the STATS instantiation of the same kernel (it derives the probe counts from the

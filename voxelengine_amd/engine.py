@@ -319,6 +319,13 @@ class Context:
         N.check(self._L.vxrt_synchronize(self._h))
 
 
+def grid_is_wide(cdims) -> bool:
+    """The rule of csrc/vxrt_device.hpp (grid_is_wide): a coarse grid beyond the tracer's packed step counters -- more than
+    1020 / 508 / 1020 cells, or one a single walk could cross in MAX_STEPS iterations -- runs the WIDE instantiation."""
+    cx, cy, cz = (int(c) for c in cdims)
+    return cx > 1020 or cz > 1020 or cy > 508 or cx + cy + cz + 4 >= 2048
+
+
 def _ptr(x):
     if x is None:
         return None
