@@ -158,10 +158,6 @@ __device__ __forceinline__ const RenderArgs& kernarg_reload(const RenderArgs& in
 #ifndef VXRT_SUBROUNDS2
 #define VXRT_SUBROUNDS2 3
 #endif
-// probe pairs per round after the tile queue has run dry (0: the same as before)
-#ifndef VXRT_TAIL_PAIRS
-#define VXRT_TAIL_PAIRS 0
-#endif
 #ifndef VXRT_VOTE2_NEXT
 #define VXRT_VOTE2_NEXT 2
 #endif
@@ -559,15 +555,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         // A round = the cascade above (box, end, next), then VXRT_SUBROUNDS2 probe pairs back to back: the walking mask is
         // carried from probe to probe in scalar registers, the ballots and branches of a vote are paid once per round
         // (votes between the pairs only split the phases' lanes: -5 %, profiles/r03_variant7.md)
-#if VXRT_TAIL_PAIRS > 0
-        // Once the tile queue has run dry the wave is no longer working for throughput but down its longest pixel chain: a lane
-        // that parks in the first probe of a burst would wait through the rest of the burst for its phase.  So the tail runs
-        // VXRT_TAIL_PAIRS pair(s) per round (profiles/r04_tail.md).
-        if (drained)
-            T.template probe_pairs<VXRT_TAIL_PAIRS, STATS>(W);
-        else
-#endif
-            T.template probe_pairs<VXRT_SUBROUNDS2, STATS>(W);
+        // (Measured and not kept, profiles/r04_tail.md: one or two pairs per round once the tile queue has run dry -- on the idea
+        // that the tail is a latency problem -- 16 views per launch -2.3 %, one view per launch -5 %; leaving a burst as soon as
+        // no lane walks any more: -0.8 % / +-0.)
+        T.template probe_pairs<VXRT_SUBROUNDS2, STATS>(W);
     }
 
     if (lane == 0) {

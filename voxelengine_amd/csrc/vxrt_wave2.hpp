@@ -723,10 +723,6 @@ struct WaveTracerT {
             hits |= h1 | h2;
             other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
             w = w2 & ~(h2 | sus2 | gd2);
-#ifdef VXRT_BURST_EARLY_EXIT
-            if (k + 1 < PAIRS && w == 0ull)  // (A/B knob: nobody walks any more, back to the votes)
-                break;
-#endif
         }
         const lanemask_t park = hits & ~fine_m, lhit = hits & fine_m;
         unsigned long long save;
