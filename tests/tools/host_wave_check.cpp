@@ -98,6 +98,8 @@ int main(int argc, char** argv)
         // long walks along the long axis (wide grids: the packed counters are re-armed, a walk of MAX_STEPS steps ends the ray)
         if (i % 5 == 0 && S > 4 * Sy) { d[0] = (i & 8) ? 1.0f : -1.0f; d[1] *= 0.002f; d[2] *= 0.002f; if (i % 10 == 0) o[0] = d[0] > 0 ? -3.0f : S + 3.0f; }
         if (i % 29 == 0) { d[0] = (i & 1) ? 1.0f : -1.0f; d[1] = d[2] = 0; o[1] = floorf(o[1]); o[2] = floorf(o[2]); }
+        // nearly axis-parallel rays from a face: the longest accumulation of one axis' tMax (the exit threshold's margin)
+        if (i % 41 == 0) { int a = (i / 41) % 3; d[a] = (i & 2) ? 1.0f : -1.0f; d[(a + 1) % 3] *= 1e-4f; d[(a + 2) % 3] *= 1e-5f; o[a] = d[a] > 0 ? 0.0f : ext[a]; }
         int steps; float nn[3], pp[3] = {0, 0, 0}; int vox[3] = {0, 0, 0}; vxo_ray_stats st{};
         int h = vxo_raytrace(w, 2048, o, d, &steps, nn, pp, vox, &st);
         n_hits += h != 0; n_long += steps > 1024; n_exhausted += steps >= 2048 && !h;
@@ -132,6 +134,10 @@ int main(int argc, char** argv)
                    i, o[0], o[1], o[2], d[0], d[1], d[2], h, steps, (unsigned long long)st.coarse_probes, (unsigned long long)st.brick_entries,
                    (unsigned long long)st.fine_probes, pp[0], pp[1], pp[2], vox[0], vox[1], vox[2], t4.hit, t4.steps, c4.coarse_probes, c4.brick_entries,
                    c4.fine_probes, t4.pos.x, t4.pos.y, t4.pos.z, t4.vx, t4.vy, t4.vz, (int)same(t5, c5), (int)same(t1, c1), (int)same(t6, c6), t6.hit, t6.steps, t6.pos.x, t6.pos.y, t6.pos.z);
+    }
+    if (host_unsuspected_exits() != 0) {   // a lane left a grid without passing its walk's time threshold: the GPU probe would walk on
+        printf("UNSUSPECTED EXITS: %llu\n", host_unsuspected_exits());
+        bad += 1;
     }
     printf("mismatches %d of %d  (hits %d, rays of more than 1024 steps %d, of 2048 or more without a hit %d; loads in the tables' slack %llu, outside it %llu)\n", bad, n, n_hits, n_long, n_exhausted, slack_loads, stray_loads);
     return bad != 0;

@@ -65,6 +65,15 @@ enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u, ST_IDLE 
 // voxel, a coarse walk that steps out of the world -- settled by the caller's ray-finished phase instead of an end-of-walk
 // phase of their own: 36 % fewer end-of-walk executions, but the finished lanes then idle until the rarer ray-finished phase
 // runs; 16 views per launch 7127 against 7164 Mrays/s.)
+// A/B knob: 1 = the probes of ordinary grids test rem's guard bits too (as in round 3)
+#ifndef VXRT_PROBE_GD
+#define VXRT_PROBE_GD 0
+#endif
+#ifdef VXRT_HOST_CHECK
+// host harness: advances that left a grid without being beyond the walk's time threshold (must stay 0 on ordinary grids)
+inline unsigned long long& host_unsuspected_exits() { static unsigned long long n = 0; return n; }
+#endif
+
 // unit normals as small codes: 0 = zero vector, (axis+1) | 4*negative
 __device__ __forceinline__ f3 normal_decode(uint32_t c)
 {
@@ -95,7 +104,13 @@ enum : int {
 
 constexpr uint32_t kRemDecX = 1u, kRemDecY = 1u << 11, kRemDecZ = 1u << 21;
 constexpr uint32_t kRemGuards = (1u << 10) | (1u << 20) | (1u << 31);
-constexpr float kThrEps = 9.5367431640625e-07f;  // 2^-20: relative margin of the region-check thresholds
+// Relative margins of the walk's time threshold t_hi.  Since round 4 the threshold is also what stops a lane that leaves its
+// grid on ordinary grids (the probe no longer tests rem's guard bits there), so the margin must cover the worst drift between
+// the DDA's accumulated t of the exit step -- tMax_k after n_k additions of |1/d_k|, each rounded: at most (n_k + 5) * 2^-24
+// relative, n_k <= 32 steps along an axis in a brick, <= 1020 on an ordinary coarse grid -- and the directly computed exit
+// time (bound_k - s_k) * (1/d_k): 2^-17 for brick walks (37 * 2^-24 < 2^-18.7), 2^-13 for coarse ones (1025 * 2^-24 < 2^-13.9).
+constexpr float kThrEpsFine = 7.62939453125e-06f;     // 2^-17
+constexpr float kThrEpsCoarse = 1.220703125e-04f;     // 2^-13
 constexpr float kMinFastDir = 9.094947017729282e-13f;  // 2^-40: smallest direction component begin_walk_fast divides by
 
 // The machine's min / max as single instructions (fminf / fmaxf compile to the instruction plus one canonicalising
@@ -306,7 +321,7 @@ struct WaveTracerT {
         // does not change the clamped cell.  If there is one such axis and it is the DDA's first choice, the probes handle
         // it (idx gets `fix` subtracted after the first advance); anything else goes to single-step mode.
         const uint32_t ex = (uint32_t)(c_x - q_x), ey = (uint32_t)(c_y - q_y), ez = (uint32_t)(c_z - q_z);
-        bool single = FINE && special;
+        bool single = special;
         fix = 0u;
         if (__ballot(inside && (ex | ey | ez) != 0u) != 0ull) {
             const bool a0 = tn_x < tn_y && tn_x < tn_z;
@@ -317,20 +332,21 @@ struct WaveTracerT {
             fix = simple ? (((0u - ex) & di_x) | ((0u - ey) & di_y) | ((0u - ez) & di_z)) : 0u;
             single = single || (npend != 0u && !simple);
         }
-        float hi_t = kInf;
+        // The walk's time threshold.  Component k of the crossing point, start_k + (t * d_k), is monotone in t; on its exit
+        // side it stays inside the level's grid until t = (bound_k - s_k) / d_k, bound = the dimension (up) or 0.  A brick
+        // walk's region check (:325-341) can only fail beyond the minimum over the axes, and NO walk can leave its grid before
+        // it; with the margin of kThrEps* towards the inside the probe's one compare of t against it catches both.  (A step
+        // along k itself is not checked against k's own bound by the reference, but a step that is later than this along
+        // another axis is rare enough -- the lane is about to leave through k -- to be validated one by one.)
+        const uint32_t bxb = __float_as_uint(FINE ? W.ff : (float)W.cx), byb = __float_as_uint(FINE ? W.ff : (float)W.cy),
+                       bzb = __float_as_uint(FINE ? W.ff : (float)W.cz);
+        const float hx = (__uint_as_float(bxb & mx) - s.x) * ivx, hy = (__uint_as_float(byb & my) - s.y) * ivy,
+                    hz = (__uint_as_float(bzb & mz) - s.z) * ivz;
+        float hi_t = vmin3(hx, hy, hz);
+        hi_t = hi_t - fabsf(hi_t) * (FINE ? kThrEpsFine : kThrEpsCoarse);
+        // (a direction component below 2^-40 makes its quotient overflow, inf - inf above: such rays validate every step)
+        hi_t = special ? -kInf : hi_t;
         if (FINE) {
-            // Region check of a brick walk (:325-341): component k of the crossing point, start_k + (t * d_k), is monotone
-            // in t; on its exit side it stays inside until t = (bound_k - s_k) / d_k, bound = f (up) or 0.  The threshold
-            // carries a relative margin of 2^-20 towards the inside, far more than the two roundings of the expression can
-            // move it.  A step along k itself is not checked against k's own bound by the reference, but a step that is
-            // later than this along another axis is rare enough (the lane is within 1e-6 of leaving through k) to be
-            // validated one by one.
-            const uint32_t Fb = __float_as_uint(W.ff);
-            const float hx = (__uint_as_float(Fb & mx) - s.x) * ivx, hy = (__uint_as_float(Fb & my) - s.y) * ivy,
-                        hz = (__uint_as_float(Fb & mz) - s.z) * ivz;
-            hi_t = vmin3(hx, hy, hz);
-            hi_t = hi_t - fabsf(hi_t) * kThrEps;
-            hi_t = special ? -kInf : hi_t;
             // entry side: a start outside [0, f] on some axis (sign bit of s_k or of f - s_k)
             const uint32_t out = __float_as_uint(s.x) | __float_as_uint(s.y) | __float_as_uint(s.z) | __float_as_uint(W.ff - s.x) |
                                  __float_as_uint(W.ff - s.y) | __float_as_uint(W.ff - s.z);
@@ -679,7 +695,9 @@ struct WaveTracerT {
                 idx -= fix;
                 fix = 0u;
             }
-            const bool sus = tl > t_hi, gd = (rem & kRemGuards) != 0u;
+            const bool sus = !(tl < t_hi), gd = WIDE && (rem & kRemGuards) != 0u;  // (ordinary grids: t_hi stops a lane that leaves)
+            if (!WIDE && (rem & kRemGuards) != 0u && !sus)  // the invariant the GPU probe relies on, counted by the host harness
+                host_unsuspected_exits() += 1;
             const bool solid = ((word >> (i1 & 31u)) & 1u) != 0u;
             if (solid)
                 st = lane_fine() ? (uint32_t)ST_ENDHIT : (uint32_t)ST_BOX;
@@ -700,7 +718,7 @@ struct WaveTracerT {
             const uint32_t word1 = *a1;
             if (GUARD)
                 guard_load(W, a1);
-            advance(w, sus1, gd1);
+            advance<WIDE || VXRT_PROBE_GD>(w, sus1, gd1);
             if (k == 0) {
                 idx -= fix;
                 fix = 0u;
@@ -718,7 +736,7 @@ struct WaveTracerT {
             // ---- probe 1: who stood on an occupied cell
             const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w;
             const lanemask_t w2 = w & ~(h1 | sus1 | gd1);
-            advance(w2, sus2, gd2);
+            advance<WIDE || VXRT_PROBE_GD>(w2, sus2, gd2);
             const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
             hits |= h1 | h2;
             other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
@@ -752,50 +770,68 @@ struct WaveTracerT {
 #ifndef VXRT_HOST_CHECK
     // One speculative DDA advance (:293-322) of the lanes in `w`, in place.  Outputs (limited to w): sus = lanes whose t
     // is beyond t_hi, gd = lanes with a guard bit in rem (the advance left the grid).
+    //
+    // GD: also test rem's guard bits.  Only the wide-grid instantiation needs it (a virtual face is not where t_hi expects the
+    // grid to end); on ordinary grids a lane that leaves its grid is always beyond t_hi (kThrEps*), which saves the probe one
+    // fast and one slow vector instruction and the mask arithmetic behind them.
+#define VXRT_ADVANCE_ASM(GUARD_PART)                                                                                     \
+            "s_mov_b64 %[save], exec\n\t"                                                                                \
+            "s_mov_b64 exec, %[w]\n\t"                                                                                   \
+            /* compares of the three tMax under w: their masks are limited to w */                                        \
+            "v_cmp_lt_f32 s[84:85], %[tx], %[ty]\n\t"                                                                    \
+            "v_cmp_lt_f32 s[86:87], %[tx], %[tz]\n\t"                                                                    \
+            "v_cmp_lt_f32 s[88:89], %[ty], %[tz]\n\t"                                                                    \
+            /* history, then t of this advance */                                                                         \
+            "v_mov_b32 %[tp], %[tl]\n\t"                                                                                 \
+            "v_mov_b32 %[rpp], %[rp]\n\t"                                                                                \
+            "v_mov_b32 %[rp], %[rem]\n\t"                                                                                \
+            "v_min3_f32 %[tl], %[tx], %[ty], %[tz]\n\t"                                                                  \
+            /* x: tx < ty && tx < tz; y: !(tx < ty) && ty < tz; z: the rest of w */                                       \
+            "s_and_b64 s[86:87], s[84:85], s[86:87]\n\t"                                                                 \
+            "s_andn2_b64 s[88:89], s[88:89], s[84:85]\n\t"                                                               \
+            "s_or_b64 s[84:85], s[86:87], s[88:89]\n\t"                                                                  \
+            "s_andn2_b64 s[84:85], %[w], s[84:85]\n\t"                                                                   \
+            "s_mov_b64 exec, s[86:87]\n\t"                                                                               \
+            "v_add_f32 %[tx], %[tx], |%[ivx]|\n\t"                                                                       \
+            "v_add_u32 %[idx], %[idx], %[dix]\n\t"                                                                       \
+            "v_add_u32 %[rem], -1, %[rem]\n\t"                                                                           \
+            "s_mov_b64 exec, s[88:89]\n\t"                                                                               \
+            "v_add_f32 %[ty], %[ty], |%[ivy]|\n\t"                                                                       \
+            "v_add_u32 %[idx], %[idx], %[diy]\n\t"                                                                       \
+            "v_add_u32 %[rem], 0xfffff800, %[rem]\n\t"                                                                   \
+            "s_mov_b64 exec, s[84:85]\n\t"                                                                               \
+            "v_add_f32 %[tz], %[tz], |%[ivz]|\n\t"                                                                       \
+            "v_add_u32 %[idx], %[idx], %[diz]\n\t"                                                                       \
+            "v_add_u32 %[rem], 0xffe00000, %[rem]\n\t"                                                                   \
+            "s_mov_b64 exec, %[w]\n\t"                                                                                   \
+            /* not less than: a start ON its exit face has t_hi = 0 and leaves with t = 0 */                              \
+            "v_cmp_nlt_f32 %[sus], %[tl], %[thi]\n\t"                                                                    \
+            GUARD_PART                                                                                                    \
+            "s_mov_b64 exec, %[save]"
+    template <bool GD>
     __device__ __forceinline__ void advance(const lanemask_t w, lanemask_t& sus, lanemask_t& gd)
     {
         unsigned long long save;
+        if (!GD) {
+            asm volatile(VXRT_ADVANCE_ASM("")
+                         : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
+                           [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [save] "=&s"(save)
+                         : [w] "s"(w), [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [dix] "v"(di_x), [diy] "v"(di_y), [diz] "v"(di_z),
+                           [thi] "v"(t_hi)
+                         : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
+            gd = 0ull;
+            return;
+        }
         uint32_t tmp;
-        asm volatile(
-            "s_mov_b64 %[save], exec\n\t"
-            "s_mov_b64 exec, %[w]\n\t"
-            // compares of the three tMax under w: their masks are limited to w
-            "v_cmp_lt_f32 s[84:85], %[tx], %[ty]\n\t"
-            "v_cmp_lt_f32 s[86:87], %[tx], %[tz]\n\t"
-            "v_cmp_lt_f32 s[88:89], %[ty], %[tz]\n\t"
-            // history, then t of this advance
-            "v_mov_b32 %[tp], %[tl]\n\t"
-            "v_mov_b32 %[rpp], %[rp]\n\t"
-            "v_mov_b32 %[rp], %[rem]\n\t"
-            "v_min3_f32 %[tl], %[tx], %[ty], %[tz]\n\t"
-            // x: tx < ty && tx < tz; y: !(tx < ty) && ty < tz; z: the rest of w
-            "s_and_b64 s[86:87], s[84:85], s[86:87]\n\t"
-            "s_andn2_b64 s[88:89], s[88:89], s[84:85]\n\t"
-            "s_or_b64 s[84:85], s[86:87], s[88:89]\n\t"
-            "s_andn2_b64 s[84:85], %[w], s[84:85]\n\t"
-            "s_mov_b64 exec, s[86:87]\n\t"
-            "v_add_f32 %[tx], %[tx], |%[ivx]|\n\t"
-            "v_add_u32 %[idx], %[idx], %[dix]\n\t"
-            "v_add_u32 %[rem], -1, %[rem]\n\t"
-            "s_mov_b64 exec, s[88:89]\n\t"
-            "v_add_f32 %[ty], %[ty], |%[ivy]|\n\t"
-            "v_add_u32 %[idx], %[idx], %[diy]\n\t"
-            "v_add_u32 %[rem], 0xfffff800, %[rem]\n\t"
-            "s_mov_b64 exec, s[84:85]\n\t"
-            "v_add_f32 %[tz], %[tz], |%[ivz]|\n\t"
-            "v_add_u32 %[idx], %[idx], %[diz]\n\t"
-            "v_add_u32 %[rem], 0xffe00000, %[rem]\n\t"
-            "s_mov_b64 exec, %[w]\n\t"
-            "v_cmp_gt_f32 %[sus], %[tl], %[thi]\n\t"
-            "v_and_b32 %[tmp], 0x80100400, %[rem]\n\t"
-            "v_cmp_ne_u32 %[gd], 0, %[tmp]\n\t"
-            "s_mov_b64 exec, %[save]"
-            : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
-              [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [gd] "=&s"(gd), [save] "=&s"(save), [tmp] "=&v"(tmp)
-            : [w] "s"(w), [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [dix] "v"(di_x), [diy] "v"(di_y), [diz] "v"(di_z),
-              [thi] "v"(t_hi)
-            : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
+        asm volatile(VXRT_ADVANCE_ASM("v_and_b32 %[tmp], 0x80100400, %[rem]\n\t"
+                                      "v_cmp_ne_u32 %[gd], 0, %[tmp]\n\t")
+                     : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
+                       [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [gd] "=&s"(gd), [save] "=&s"(save), [tmp] "=&v"(tmp)
+                     : [w] "s"(w), [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [dix] "v"(di_x), [diy] "v"(di_y), [diz] "v"(di_z),
+                       [thi] "v"(t_hi)
+                     : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
     }
+#undef VXRT_ADVANCE_ASM
 #endif
 
     // Raytrace's epilogue (:514-523); the ray has ended (st == ST_DONE)
