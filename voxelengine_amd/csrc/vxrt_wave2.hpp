@@ -340,13 +340,8 @@ struct WaveTracerT {
         // another axis is rare enough -- the lane is about to leave through k -- to be validated one by one.)
         // (coarse: the world box's far corner, dims - 1e-6 rounded to binary32 (:375-376), is at or just inside the grid's far
         // faces -- a threshold a hair earlier is as good, and the value is in a scalar register already)
-#ifdef VXRT_THI_FROM_DIMS  // (A/B knob: the exact dimensions, converted in the phase)
-        const uint32_t bxb = __float_as_uint(FINE ? W.ff : (float)W.cx), byb = __float_as_uint(FINE ? W.ff : (float)W.cy),
-                       bzb = __float_as_uint(FINE ? W.ff : (float)W.cz);
-#else
         const uint32_t bxb = __float_as_uint(FINE ? W.ff : W.wmax_x), byb = __float_as_uint(FINE ? W.ff : W.wmax_y),
                        bzb = __float_as_uint(FINE ? W.ff : W.wmax_z);
-#endif
         const float hx = (__uint_as_float(bxb & mx) - s.x) * ivx, hy = (__uint_as_float(byb & my) - s.y) * ivy,
                     hz = (__uint_as_float(bzb & mz) - s.z) * ivz;
         float hi_t = vmin3(hx, hy, hz);
