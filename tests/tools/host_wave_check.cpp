@@ -71,7 +71,7 @@ int main(int argc, char** argv)
         TP.after_begin_ray(true);
         for (;;) {   // the cascade of the persistent kernels: tight box, end of walk, (ray finished), probes
             if (TP.st == ST_BOX) TP.template phase_box<true>(W);
-            if (TP.st == ST_END || TP.st == ST_ENDHIT) TP.template phase_end<true>(W);
+            if (waits_for_end(TP.st)) TP.template phase_end<true>(W);
             if (TP.st == ST_DONE) break;
             TP.template probe_pairs<2, true>(W);
         }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        const unsigned long long m_end = __ballot(waits_for_end(T.st));
         const unsigned long long m_next = __ballot(T.st == ST_DONE);
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             T.template phase_box<STATS>(W);
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+            c_end = __popcll(__ballot(waits_for_end(T.st)));
         }
         if (vote_run(c_end, c_walk + c_box, VXRT_BATCH_VOTE_END)) {
             T.template phase_end<STATS>(W);

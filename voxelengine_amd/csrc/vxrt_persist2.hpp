@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        const unsigned long long m_end = __ballot(waits_for_end(T.st));
         const unsigned long long m_next = __ballot(T.st == ST_DONE);
         if ((m_walk | m_box | m_end | m_next) == 0ull)
             break;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                 dg_park_ticks += wall_clock64();
             c_box = 0;
             c_walk = __popcll(__ballot(T.st == ST_WALK));
-            c_end = __popcll(__ballot(T.st == ST_END || T.st == ST_ENDHIT));
+            c_end = __popcll(__ballot(waits_for_end(T.st)));
         }
         if (vote2(c_end, c_walk + c_box, VXRT_VOTE2_END, VXRT_VOTE2_ABS_END)) {
             if (STATS) {

@@ -58,9 +58,12 @@
 
 namespace vxrt {
 
-// lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase; ray finished; no work left;
-// parked for the end-of-walk phase after a brick probe that found an occupied voxel
-enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_DONE = 3u, ST_IDLE = 4u, ST_ENDHIT = 5u };
+// lane states: walking; parked for the tight-box phase; parked for the end-of-walk phase (ST_END, and ST_ENDHIT after a brick
+// probe that found an occupied voxel: the two codes differ in bit 0 only, so "waits for the end-of-walk phase" is one OR and
+// one compare -- written as `a || b` the vote's ballot compiled to two compares, a select and a third compare); ray finished;
+// no work left
+enum : uint32_t { ST_WALK = 0u, ST_BOX = 1u, ST_END = 2u, ST_ENDHIT = 3u, ST_DONE = 4u, ST_IDLE = 5u };
+__device__ __forceinline__ bool waits_for_end(uint32_t st) { return (st | 1u) == 3u; }
 // (Measured in round 4 and not kept, profiles/r04_finish_walks.md: the two common ends of a ray -- a brick probe that finds a
 // voxel, a coarse walk that steps out of the world -- settled by the caller's ray-finished phase instead of an end-of-walk
 // phase of their own: 36 % fewer end-of-walk executions, but the finished lanes then idle until the rarer ray-finished phase
@@ -82,8 +85,10 @@ __device__ __forceinline__ f3 normal_decode(uint32_t c)
     return mk3(a == 1u ? v : 0.0f, a == 2u ? v : 0.0f, a == 3u ? v : 0.0f);
 }
 
-// a parked phase runs when its lanes, times `num`, are at least the other live lanes (or nobody else can move)
-__device__ __forceinline__ bool vote_run(int parked, int others, int num) { return parked > 0 && parked * num >= others; }
+// a parked phase runs when its lanes, times `num`, are at least the other live lanes (or nobody else can move): parked > 0
+// and parked * num >= others, as ONE scalar comparison (the two-condition form compiled to two compare + select pairs and an
+// and of masks per vote, and a round has five votes)
+__device__ __forceinline__ bool vote_run(int parked, int others, int num) { return parked * num >= max(others, 1); }
 // thresholds of trace_wave2 (one ray per lane: the batch kernel for small batches, the host harness)
 #ifndef VXRT_VOTE_END
 #define VXRT_VOTE_END 2
@@ -128,6 +133,17 @@ __device__ __forceinline__ float vmin3(float a, float b, float c) { return vmin(
 __device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
 #endif
 
+// bit (index mod 32) of a word: v_bfe_u32 takes the offset from the low five bits of its operand, so the index needs no mask
+#ifndef VXRT_HOST_CHECK
+__device__ __forceinline__ uint32_t bit_of(uint32_t word, uint32_t index)
+{
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, 1" : "=v"(r) : "v"(word), "v"(index));
+    return r;
+}
+#else
+__device__ __forceinline__ uint32_t bit_of(uint32_t word, uint32_t index) { return (word >> (index & 31u)) & 1u; }
+#endif
 __device__ __forceinline__ uint32_t rem_fx(uint32_t r) { return r & 0x7FFu; }
 __device__ __forceinline__ uint32_t rem_fy(uint32_t r) { return (r >> 11) & 0x3FFu; }
 __device__ __forceinline__ uint32_t rem_fz(uint32_t r) { return r >> 21; }
@@ -428,7 +444,7 @@ struct WaveTracerT {
     template <bool STATS = false>
     __device__ __forceinline__ void phase_end(const WorldView& W)
     {
-        const bool me = st == ST_END || st == ST_ENDHIT;
+        const bool me = waits_for_end(st);
         const bool is_fine = lane_fine();
         bool go_coarse = false;  // this lane restarts the coarse walk
         if (me) {
@@ -736,10 +752,10 @@ struct WaveTracerT {
             if (GUARD)
                 guard_load(W, a2);
             // ---- probe 1: who stood on an occupied cell
-            const lanemask_t h1 = lane_mask(((word1 >> (i1 & 31u)) & 1u) != 0u) & w;
+            const lanemask_t h1 = lane_mask(bit_of(word1, i1) != 0u) & w;
             const lanemask_t w2 = w & ~(h1 | sus1 | gd1);
             advance<WIDE || VXRT_PROBE_GD>(w2, sus2, gd2);
-            const lanemask_t h2 = lane_mask(((word2 >> (i2 & 31u)) & 1u) != 0u) & w2;
+            const lanemask_t h2 = lane_mask(bit_of(word2, i2) != 0u) & w2;
             hits |= h1 | h2;
             other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
             w = w2 & ~(h2 | sus2 | gd2);
@@ -750,13 +766,13 @@ struct WaveTracerT {
                      "s_mov_b64 exec, %[park]\n\t"
                      "v_mov_b32 %[st], 1\n\t"
                      "s_mov_b64 exec, %[lhit]\n\t"
-                     "v_mov_b32 %[st], 5\n\t"
+                     "v_mov_b32 %[st], 3\n\t"
                      "s_mov_b64 exec, %[other]\n\t"
                      "v_mov_b32 %[st], 2\n\t"
                      "s_mov_b64 exec, %[save]"
                      : [st] "+v"(st), [save] "=&s"(save)
                      : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
-        static_assert(ST_BOX == 1u && ST_ENDHIT == 5u && ST_END == 2u, "state codes of the asm above");
+        static_assert(ST_BOX == 1u && ST_ENDHIT == 3u && ST_END == 2u, "state codes of the asm above");
 #endif
     }
 
@@ -878,7 +894,7 @@ __device__ inline void trace_wave2(const WorldView& W, const int max_steps, cons
     for (;;) {
         const unsigned long long m_walk = __ballot(T.st == ST_WALK);
         const unsigned long long m_box = __ballot(T.st == ST_BOX);
-        const unsigned long long m_end = __ballot(T.st == ST_END || T.st == ST_ENDHIT);
+        const unsigned long long m_end = __ballot(waits_for_end(T.st));
         if ((m_walk | m_box | m_end) == 0ull)
             break;
         const int n_walk = __popcll(m_walk), n_box = __popcll(m_box), n_end = __popcll(m_end);
