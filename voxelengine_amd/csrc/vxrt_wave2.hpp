@@ -723,8 +723,8 @@ struct WaveTracerT {
                 st = ST_END;
         }
 #else
-        lanemask_t w = lane_mask(st == ST_WALK);
-        lanemask_t hits = 0ull, other = 0ull;
+        const lanemask_t w0 = lane_mask(st == ST_WALK);
+        lanemask_t w = w0, hits = 0ull;
 #pragma unroll
         for (int k = 0; k < PAIRS; ++k) {
             lanemask_t sus1, gd1, sus2, gd2;
@@ -757,20 +757,22 @@ struct WaveTracerT {
             advance<WIDE || VXRT_PROBE_GD>(w2, sus2, gd2);
             const lanemask_t h2 = lane_mask(bit_of(word2, i2) != 0u) & w2;
             hits |= h1 | h2;
-            other |= ((sus1 | gd1) & ~h1) | ((sus2 | gd2) & ~h2);
             w = w2 & ~(h2 | sus2 | gd2);
         }
+        // (who stopped without standing on an occupied cell: everyone who walked in and does not walk out, minus the hits -- a lane
+        // that is beyond t_hi on an occupied cell counts as a hit)
+        const lanemask_t other = (w0 & ~w) & ~hits;
         const lanemask_t park = hits & ~fine_m, lhit = hits & fine_m;
-        unsigned long long save;
-        asm volatile("s_mov_b64 %[save], exec\n\t"
-                     "s_mov_b64 exec, %[park]\n\t"
+        // (exec is all ones here and in `advance`: the probes run where the wave is converged and every kernel that uses this
+        // tracer launches whole wavefronts, so the asm restores -1 instead of saving and restoring the mask)
+        asm volatile("s_mov_b64 exec, %[park]\n\t"
                      "v_mov_b32 %[st], 1\n\t"
                      "s_mov_b64 exec, %[lhit]\n\t"
                      "v_mov_b32 %[st], 3\n\t"
                      "s_mov_b64 exec, %[other]\n\t"
                      "v_mov_b32 %[st], 2\n\t"
-                     "s_mov_b64 exec, %[save]"
-                     : [st] "+v"(st), [save] "=&s"(save)
+                     "s_mov_b64 exec, -1"
+                     : [st] "+v"(st)
                      : [park] "s"(park), [lhit] "s"(lhit), [other] "s"(other));
         static_assert(ST_BOX == 1u && ST_ENDHIT == 3u && ST_END == 2u, "state codes of the asm above");
 #endif
@@ -793,7 +795,6 @@ struct WaveTracerT {
     // grid to end); on ordinary grids a lane that leaves its grid is always beyond t_hi (kThrEps*), which saves the probe one
     // fast and one slow vector instruction and the mask arithmetic behind them.
 #define VXRT_ADVANCE_ASM(GUARD_PART)                                                                                     \
-            "s_mov_b64 %[save], exec\n\t"                                                                                \
             "s_mov_b64 exec, %[w]\n\t"                                                                                   \
             /* compares of the three tMax under w: their masks are limited to w */                                        \
             "v_cmp_lt_f32 s[84:85], %[tx], %[ty]\n\t"                                                                    \
@@ -825,15 +826,14 @@ struct WaveTracerT {
             /* not less than: a start ON its exit face has t_hi = 0 and leaves with t = 0 */                              \
             "v_cmp_nlt_f32 %[sus], %[tl], %[thi]\n\t"                                                                    \
             GUARD_PART                                                                                                    \
-            "s_mov_b64 exec, %[save]"
+            "s_mov_b64 exec, -1"
     template <bool GD>
     __device__ __forceinline__ void advance(const lanemask_t w, lanemask_t& sus, lanemask_t& gd)
     {
-        unsigned long long save;
         if (!GD) {
             asm volatile(VXRT_ADVANCE_ASM("")
                          : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
-                           [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [save] "=&s"(save)
+                           [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus)
                          : [w] "s"(w), [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [dix] "v"(di_x), [diy] "v"(di_y), [diz] "v"(di_z),
                            [thi] "v"(t_hi)
                          : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
@@ -844,7 +844,7 @@ struct WaveTracerT {
         asm volatile(VXRT_ADVANCE_ASM("v_and_b32 %[tmp], 0x80100400, %[rem]\n\t"
                                       "v_cmp_ne_u32 %[gd], 0, %[tmp]\n\t")
                      : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
-                       [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [gd] "=&s"(gd), [save] "=&s"(save), [tmp] "=&v"(tmp)
+                       [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [gd] "=&s"(gd), [tmp] "=&v"(tmp)
                      : [w] "s"(w), [ivx] "v"(ivx), [ivy] "v"(ivy), [ivz] "v"(ivz), [dix] "v"(di_x), [diy] "v"(di_y), [diz] "v"(di_z),
                        [thi] "v"(t_hi)
                      : "s84", "s85", "s86", "s87", "s88", "s89", "scc");
