@@ -678,6 +678,9 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     A.shadow = fl->shadow ? 1 : 0;
     A.bounce_samples = fl->bounce_samples < 0 ? 0 : fl->bounce_samples;
     A.bounce_samples_f = (float)A.bounce_samples;
+    A.inv_width = 1.0f / (float)(int)width;
+    A.inv_height = 1.0f / (float)(int)height;
+    A.inv_bounce_samples = A.bounce_samples > 0 ? 1.0f / A.bounce_samples_f : 0.0f;
     A.bounce_all_hits = fl->bounce_all_hits ? 1 : 0;
     A.bounce_depth = fl->bounce_depth >= 2 ? 2 : 1;
     A.ortho = fl->ortho ? 1 : 0;

@@ -39,6 +39,50 @@ __device__ __forceinline__ float lo(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float hi(float a, float b) { return a > b ? a : b; }
 // normalize: v * (1/sqrt(dot)) with correctly rounded sqrt and divide (helper_math.h:78-81,1325-1329)
 __device__ __forceinline__ f3 unit3(f3 v) { return v * (1.0f / sqrtf(dot3(v, v))); }
+
+// ---- correctly rounded reciprocal, square root and quotient in 3 / 8 / 3 instructions, for operands of ordinary size
+// hipcc's IEEE division is v_div_scale x 2, v_rcp, 4 FMAs, v_div_fmas, v_div_fixup (10 instructions) and its sqrtf 15; the
+// ray-finished phase of the render kernel runs thirteen divisions and four square roots per execution.  On operands whose
+// exponent lies in [-100, 100] the hardware's v_rcp_f32 + one Newton step IS the correctly rounded reciprocal and
+// v_rsq_f32 + 7 FMA-class instructions IS the correctly rounded square root -- checked on the GPU against the IEEE
+// operators for EVERY such binary32 (tools/ubench/rcp_check.hip) -- and with the correctly rounded reciprocal y of b,
+// q' = RN(q + RN(a - b q) y), q = RN(a y), is the correctly rounded quotient (Markstein; checked on the CPU for every operand
+// pair of the families the kernel uses it on and 10^9 random pairs, tests/tools/exact_div_check.c).  Callers vote on
+// `ordinary` and run the plain operators when any lane's operand is outside (never, on the frames of the tests).
+#ifndef VXRT_HOST_CHECK
+__device__ __forceinline__ float hw_rcp(float x) { float r; asm("v_rcp_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ float hw_rsq(float x) { float r; asm("v_rsq_f32 %0, %1" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ float rcp_rn(float x)
+{
+    const float y = hw_rcp(x);
+    return fmaf(fmaf(-x, y, 1.0f), y, y);
+}
+__device__ __forceinline__ float sqrt_rn(float x)
+{
+    const float r = hw_rsq(x);
+    float g = x * r, h = 0.5f * r;
+    const float e = fmaf(-h, g, 0.5f);
+    g = fmaf(g, e, g);
+    h = fmaf(h, e, h);
+    return fmaf(fmaf(-g, g, x), h, g);
+}
+#else
+__device__ __forceinline__ float rcp_rn(float x) { return 1.0f / x; }
+__device__ __forceinline__ float sqrt_rn(float x) { return sqrtf(x); }
+#endif
+// a / b given y = rcp_rn(b)
+__device__ __forceinline__ float div_rn(float a, float b, float y)
+{
+    const float q = a * y;
+    return fmaf(fmaf(-b, q, a), y, q);
+}
+// exponent in [-100, 100] (and not zero, infinite or NaN): one subtraction and one compare on the bits
+__device__ __forceinline__ bool ordinary(float x)
+{
+    return ((__float_as_uint(x) & 0x7FFFFFFFu) - 0x0D800000u) < (0x72000000u - 0x0D800000u);
+}
+// unit3 on a vector whose squared length is ordinary (the caller has voted on that)
+__device__ __forceinline__ f3 unit3_ordinary(f3 v, float dd) { return v * rcp_rn(sqrt_rn(dd)); }
 // reflect(i, n) = i - 2n*dot(n,i) (helper_math.h:1427-1430)
 __device__ __forceinline__ f3 reflect3(f3 i, f3 n) { return i - (n * 2.0f) * dot3(n, i); }
 

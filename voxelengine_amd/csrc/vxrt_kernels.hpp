@@ -69,6 +69,9 @@ struct RenderArgs {
     f3 light_unit;  // normalize(light_dir), the shadow ray (Renderer.cu:97): the same IEEE operations, evaluated once on the host
     f3 light_step;           // light_unit * 0.01f (the shadow ray's offset, Renderer.cu:97)
     float bounce_samples_f;  // (float)bounce_samples
+    // correctly rounded reciprocals of (float)width, (float)height and bounce_samples_f, evaluated on the host: the render
+    // kernel's x / W, y / H and occlusion mean take them with one correction step (div_rn, vxrt_device.hpp)
+    float inv_width, inv_height, inv_bounce_samples;
 };
 
 // the per-view part of RenderArgs for a launch that renders several views of the same world

@@ -89,7 +89,9 @@ struct LaneView {
 // getRayDirection / getRayDirectionOrtho (Renderer.cu:44-70)
 __device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& V, int x, int y, f3& origin, f3& ray)
 {
-    const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
+    // (x / W and y / H: small integers over small integers, by the host's reciprocals and one correction step -- exact for
+    // every such pair, tests/tools/exact_div_check.c)
+    const float u = div_rn((float)x, (float)(int)A.width, A.inv_width), v = div_rn((float)y, (float)(int)A.height, A.inv_height);
     origin = V.origin;
     if (A.ortho) {
         ray = V.fwd;
@@ -100,7 +102,11 @@ __device__ __forceinline__ void camera_ray(const RenderArgs& A, const LaneView& 
         ray.x = V.fwd.x + su * A.kx * V.right.x + sv * A.ky * V.up.x;
         ray.y = V.fwd.y + su * A.kx * V.right.y + sv * A.ky * V.up.y;
         ray.z = V.fwd.z + su * A.kx * V.right.z + sv * A.ky * V.up.z;
-        ray = unit3(ray);
+        const float dd = dot3(ray, ray);
+        const f3 plain = ray;
+        ray = unit3_ordinary(plain, dd);
+        if (__ballot(!ordinary(dd)) != 0ull)
+            ray = unit3(plain);
     }
 }
 
@@ -110,7 +116,7 @@ __device__ __forceinline__ f3 camera_origin(const RenderArgs& A, const LaneView&
 {
     f3 origin = V.origin;
     if (A.ortho) {
-        const float u = (float)x / (float)(int)A.width, v = (float)y / (float)(int)A.height;
+        const float u = div_rn((float)x, (float)(int)A.width, A.inv_width), v = div_rn((float)y, (float)(int)A.height, A.inv_height);
         origin = origin + ((V.right * (u * 2 - 1)) * A.ortho_x) * A.ratio;
         origin = origin + (V.up * (v * 2 - 1)) * A.ortho_y;
     }
@@ -262,7 +268,13 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             } else {
                 if (!MULTI && A.accum)  // temporal accumulation (extension, include/vxrt.h): the mean of the history is tonemapped
                     shaded = accumulate_color(A, pc.out_row, pc.x, shaded);
-                f3 c = mk3(shaded.x / (shaded.x + 1.0f), shaded.y / (shaded.y + 1.0f), shaded.z / (shaded.z + 1.0f));  // Tonemap
+                // Tonemap c / (c + 1) (Renderer.cu:170-177): the short exact division for colours of ordinary size (or zero)
+                const float tx = shaded.x + 1.0f, ty = shaded.y + 1.0f, tz = shaded.z + 1.0f;
+                f3 c = mk3(div_rn(shaded.x, tx, rcp_rn(tx)), div_rn(shaded.y, ty, rcp_rn(ty)), div_rn(shaded.z, tz, rcp_rn(tz)));
+                const bool plain = !(((shaded.x == 0.0f) | ordinary(shaded.x)) & ((shaded.y == 0.0f) | ordinary(shaded.y)) &
+                                     ((shaded.z == 0.0f) | ordinary(shaded.z)) & ordinary(tx) & ordinary(ty) & ordinary(tz));
+                if (__ballot(plain) != 0ull)
+                    c = mk3(shaded.x / (shaded.x + 1.0f), shaded.y / (shaded.y + 1.0f), shaded.z / (shaded.z + 1.0f));
                 c = mk3(lo(hi(c.x, 0), 1), lo(hi(c.y, 0), 1), lo(hi(c.z, 0), 1));
                 sink.put(pc.x, pc.y, c);
             }
@@ -390,7 +402,11 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                     color = diffuse + A.ambient * (0.25f + t * (1.0f - 0.25f));
                     if (!shadowed) {
                         PX_LD_POS();
-                        f3 view = unit3(position - origin);
+                        const f3 to_hit = position - origin;
+                        const float vdd = dot3(to_hit, to_hit);
+                        f3 view = unit3_ordinary(to_hit, vdd);
+                        if (__ballot(!ordinary(vdd)) != 0ull)
+                            view = unit3(to_hit);
                         f3 refl = reflect3(L, normal);
                         float spec = pow32(hi(dot3(view, refl), 0));
                         color.x += spec * A.light_color.x;
@@ -420,7 +436,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                         if (sample < A.bounce_samples) {
                             bounce = true;
                         } else {
-                            occl /= A.bounce_samples_f;
+                            occl = div_rn(occl, A.bounce_samples_f, A.inv_bounce_samples);  // (half-integers over a small integer: exact)
                             PX_LD_COL();
                             color = color * occl;
                             PX_ST_COL();
@@ -440,7 +456,13 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                     const f3 bo = mk3(bounce2 ? r.pos.x : position.x, bounce2 ? r.pos.y : position.y,
                                       bounce2 ? r.pos.z : position.z);
                     f3 sd = mk3(random_float(si) * 2 - 1, random_float(si * 10u) * 2 - 1, random_float(si * 100u) * 2 - 1);
-                    sd = unit3(sd);
+                    {
+                        const float sdd = dot3(sd, sd);
+                        const f3 raw = sd;
+                        sd = unit3_ordinary(raw, sdd);
+                        if (__ballot(!ordinary(sdd)) != 0ull)
+                            sd = unit3(raw);
+                    }
                     if (dot3(sd, bn) < 0)
                         sd = reflect3(sd, bn);
                     c_bounce = true;

@@ -381,10 +381,20 @@ struct WaveTracerT {
     // lanes' bits in fine_m afterwards (after_begin_ray), where the wave is converged again.
     __device__ __forceinline__ void begin_ray(const WorldView& W, f3 origin, f3 ray, int max_steps_)
     {
-        d = unit3(ray);
-        ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);  // :127-129
-        ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
-        ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
+        // normalize and the three reciprocals of the slab test (:127-129, :366): the short exact forms of vxrt_device.hpp where
+        // every operand is of ordinary size, the plain operators for the wave if any lane's is not
+        const float dd = dot3(ray, ray);
+        d = unit3_ordinary(ray, dd);
+        const float ex = d.x == 0 ? kFltEps : d.x, ey = d.y == 0 ? kFltEps : d.y, ez = d.z == 0 ? kFltEps : d.z;
+        ivx = rcp_rn(ex);
+        ivy = rcp_rn(ey);
+        ivz = rcp_rn(ez);
+        if (__ballot(!(ordinary(dd) & ordinary(ex) & ordinary(ey) & ordinary(ez))) != 0ull) {
+            d = unit3(ray);
+            ivx = 1.0f / (d.x == 0 ? kFltEps : d.x);
+            ivy = 1.0f / (d.y == 0 ? kFltEps : d.y);
+            ivz = 1.0f / (d.z == 0 ? kFltEps : d.z);
+        }
         f3 s0 = mk3(origin.x * W.inv_f, origin.y * W.inv_f, origin.z * W.inv_f);
         uint32_t ec = 0u;
         if (!(s0.x >= 0 && s0.y >= 0 && s0.z >= 0 && s0.x < (float)W.cx && s0.y < (float)W.cy && s0.z < (float)W.cz)) {
