@@ -437,6 +437,8 @@ struct WaveTracerT {
     __device__ __forceinline__ void walk_on(const WorldView& W, bool is_fine, bool lin_inside)
     {
         const bool single = t_hi == -kInf;
+        if (__ballot(single) == 0ull)  // (nothing to do for a lane on an ordinary walk: it keeps its idx and its threshold)
+            return;
         int x, y, z;
         cells_of(W, is_fine, rem, x, y, z);
         const int dmx = is_fine ? W.f : W.cx, dmy = is_fine ? W.f : W.cy, dmz = is_fine ? W.f : W.cz;
