@@ -812,31 +812,29 @@ struct WaveTracerT {
             "v_cmp_lt_f32 s[84:85], %[tx], %[ty]\n\t"                                                                    \
             "v_cmp_lt_f32 s[86:87], %[tx], %[tz]\n\t"                                                                    \
             "v_cmp_lt_f32 s[88:89], %[ty], %[tz]\n\t"                                                                    \
-            /* history, then t of this advance */                                                                         \
+            /* history, then t of this advance and who is beyond the threshold (not less than: a start ON its exit   */   \
+            /* face has t_hi = 0 and leaves with t = 0)                                                               */   \
             "v_mov_b32 %[tp], %[tl]\n\t"                                                                                 \
             "v_mov_b32 %[rpp], %[rp]\n\t"                                                                                \
             "v_mov_b32 %[rp], %[rem]\n\t"                                                                                \
             "v_min3_f32 %[tl], %[tx], %[ty], %[tz]\n\t"                                                                  \
-            /* x: tx < ty && tx < tz; y: !(tx < ty) && ty < tz; z: the rest of w */                                       \
-            "s_and_b64 s[86:87], s[84:85], s[86:87]\n\t"                                                                 \
-            "s_andn2_b64 s[88:89], s[88:89], s[84:85]\n\t"                                                               \
-            "s_or_b64 s[84:85], s[86:87], s[88:89]\n\t"                                                                  \
-            "s_andn2_b64 s[84:85], %[w], s[84:85]\n\t"                                                                   \
-            "s_mov_b64 exec, s[86:87]\n\t"                                                                               \
+            "v_cmp_nlt_f32 %[sus], %[tl], %[thi]\n\t"                                                                    \
+            /* x: tx < ty && tx < tz -- the mask goes straight into exec */                                               \
+            "s_and_b64 exec, s[84:85], s[86:87]\n\t"                                                                     \
             "v_add_f32 %[tx], %[tx], |%[ivx]|\n\t"                                                                       \
             "v_add_u32 %[idx], %[idx], %[dix]\n\t"                                                                       \
             "v_add_u32 %[rem], -1, %[rem]\n\t"                                                                           \
-            "s_mov_b64 exec, s[88:89]\n\t"                                                                               \
+            /* the rest of w; y: !(tx < ty) && ty < tz */                                                                 \
+            "s_andn2_b64 s[86:87], %[w], exec\n\t"                                                                       \
+            "s_andn2_b64 exec, s[88:89], s[84:85]\n\t"                                                                   \
             "v_add_f32 %[ty], %[ty], |%[ivy]|\n\t"                                                                       \
             "v_add_u32 %[idx], %[idx], %[diy]\n\t"                                                                       \
             "v_add_u32 %[rem], 0xfffff800, %[rem]\n\t"                                                                   \
-            "s_mov_b64 exec, s[84:85]\n\t"                                                                               \
+            /* z: the rest of w that is not y */                                                                          \
+            "s_andn2_b64 exec, s[86:87], exec\n\t"                                                                       \
             "v_add_f32 %[tz], %[tz], |%[ivz]|\n\t"                                                                       \
             "v_add_u32 %[idx], %[idx], %[diz]\n\t"                                                                       \
             "v_add_u32 %[rem], 0xffe00000, %[rem]\n\t"                                                                   \
-            "s_mov_b64 exec, %[w]\n\t"                                                                                   \
-            /* not less than: a start ON its exit face has t_hi = 0 and leaves with t = 0 */                              \
-            "v_cmp_nlt_f32 %[sus], %[tl], %[thi]\n\t"                                                                    \
             GUARD_PART                                                                                                    \
             "s_mov_b64 exec, -1"
     template <bool GD>
@@ -853,7 +851,8 @@ struct WaveTracerT {
             return;
         }
         uint32_t tmp;
-        asm volatile(VXRT_ADVANCE_ASM("v_and_b32 %[tmp], 0x80100400, %[rem]\n\t"
+        asm volatile(VXRT_ADVANCE_ASM("s_mov_b64 exec, %[w]\n\t"
+                                      "v_and_b32 %[tmp], 0x80100400, %[rem]\n\t"
                                       "v_cmp_ne_u32 %[gd], 0, %[tmp]\n\t")
                      : [tx] "+v"(tn_x), [ty] "+v"(tn_y), [tz] "+v"(tn_z), [idx] "+v"(idx), [rem] "+v"(rem), [rp] "+v"(rp), [rpp] "+v"(rpp),
                        [tl] "+v"(tl), [tp] "+v"(tp), [sus] "=&s"(sus), [gd] "=&s"(gd), [tmp] "=&v"(tmp)
