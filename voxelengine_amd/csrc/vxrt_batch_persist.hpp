@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
                     uint32_t t = 0;
                     if (lane == 0)
                         t = atomicAdd(B.ticket, 1u);
-                    t = (uint32_t)__shfl((int)t, 0, 64);
+                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);  // (a scalar: the queue state stays in scalar registers)
                     chunk = (unsigned long long)t * kBatchTicket;
                     if (chunk >= B.n) {
                         drained = true;

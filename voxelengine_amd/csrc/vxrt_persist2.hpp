@@ -499,7 +499,10 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
                     uint32_t t = 0;
                     if (lane == 0)
                         t = atomicAdd(A.tile_counter, 1u);
-                    tile = (uint32_t)__shfl((int)t, 0, 64);
+                    // (readfirstlane: the ticket is a scalar, so the queue state -- tile, tile_used, drained -- stays in scalar
+                    // registers and its branches are scalar branches; as a lane shuffle the compiler kept `drained` as a lane mask
+                    // that it re-merged with exec on every trip of the wave loop)
+                    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
                     if (tile >= ntiles * (MULTI ? A.nviews : 1u)) {
                         drained = true;
                         break;
