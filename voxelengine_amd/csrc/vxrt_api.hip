@@ -70,6 +70,7 @@ struct vxrt_ctx {
     unsigned persistent_waves = 4096;
     unsigned cus = 256;
     unsigned long long* d_stats = nullptr;
+    unsigned int* d_queues = nullptr;  // kTileCounterRing queue heads of vxrt::kQueueWords words (one per launch in flight)
     // Counters only ever grow on the device (atomics from any stream); "read and clear" is a host-side snapshot that the
     // next read subtracts, so nothing clears device memory under running kernels.
     unsigned long long stats_base[vxrt::kStatCount] = {};
@@ -282,12 +283,14 @@ int vxrt_create(int device, vxrt_ctx** out)
     if (!c)
         return fail(VXRT_ERR_NOMEM, "out of host memory");
     c->device = device;
-    // counters + a ring of tile counters for the persistent kernel: launches on different streams may be in flight
+    // counters, and a ring of queue heads for the persistent kernels: launches on different streams may be in flight
     // together (frame k+1 fills the SIMD slots frame k's last waves leave), each needs its own queue head
-    const size_t stat_words = vxrt::kStatCount + kTileCounterRing / 2;
+    const size_t stat_words = vxrt::kStatCount;
     hipError_t e = hipMalloc((void**)&c->d_stats, stat_words * sizeof(unsigned long long));
     if (e == hipSuccess)
         e = hipMemset(c->d_stats, 0, stat_words * sizeof(unsigned long long));
+    if (e == hipSuccess)
+        e = hipMalloc((void**)&c->d_queues, sizeof(unsigned int) * vxrt::kQueueWords * kTileCounterRing);
     if (e == hipSuccess) {
         hipDeviceProp_t prop;
         e = hipGetDeviceProperties(&prop, device);
@@ -300,6 +303,8 @@ int vxrt_create(int device, vxrt_ctx** out)
 #endif
     }
     if (e != hipSuccess) {
+        if (c->d_stats) (void)hipFree(c->d_stats);
+        if (c->d_queues) (void)hipFree(c->d_queues);
         delete c;
         return fail(VXRT_ERR_HIP, std::string("context setup: ") + hipGetErrorString(e));
     }
@@ -315,6 +320,7 @@ int vxrt_destroy(vxrt_ctx* c)
     (void)hipDeviceSynchronize();
     vxrt::free_world(c);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_queues) (void)hipFree(c->d_queues);
     if (c->d_views) (void)hipFree(c->d_views);
     for (hipEvent_t& e : c->counter_busy)
         if (e) (void)hipEventDestroy(e);
@@ -732,7 +738,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
             const unsigned slot = c->launch_seq.fetch_add(1u) % kTileCounterRing;
             bool capturing = false;
             VX_HIP(vxrt::ring_acquire(c->counter_busy[slot], stream, capturing));
-            A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + slot;
+            A.tile_counter = c->d_queues + (size_t)slot * vxrt::kQueueWords;
             VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
             VX_HIP(hipGetLastError());
             VX_HIP(vxrt::ring_release(c->counter_busy[slot], stream, capturing));
@@ -767,7 +773,7 @@ static int render_launch(vxrt_ctx* c, uint32_t width, uint32_t height, unsigned 
     VX_HIP(hipMemcpyAsync(slot, host.data(), sizeof(vxrt::ViewArgs) * n, hipMemcpyHostToDevice, stream));
     A.views = slot;
     A.nviews = n;
-    A.tile_counter = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + cslot;
+    A.tile_counter = c->d_queues + (size_t)cslot * vxrt::kQueueWords;
     VX_HIP(vxrt::launch_render(A, fl->collect_stats != 0, c->kernel_variant, stream));
     VX_HIP(hipGetLastError());
     VX_HIP(vxrt::ring_release(c->views_busy[vslot], stream, capturing));
@@ -898,7 +904,7 @@ int vxrt_trace_batch(vxrt_ctx* c, const float* d_origins, const float* d_dirs, u
     const unsigned tslot = c->launch_seq.fetch_add(1u) % kTileCounterRing;
     bool capturing = false;
     VX_HIP(vxrt::ring_acquire(c->counter_busy[tslot], stream, capturing));
-    B.ticket = reinterpret_cast<unsigned int*>(c->d_stats + vxrt::kStatCount) + tslot;
+    B.ticket = c->d_queues + (size_t)tslot * vxrt::kQueueWords;
     B.persistent_waves = c->persistent_waves;
     B.max_steps = c->batch_max_steps;
     if (stats) {  // a stats request reports what ran between two device-wide syncs: this batch alone if nothing else is submitted

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
     unsigned long long my_ray = kNone;
     unsigned long long chunk = 0;  // wave-uniform: first ray of the wave's current ticket
     uint32_t used = kBatchTicket;  // rays of the ticket already handed out
+    const uint32_t tickets = (uint32_t)((B.n + kBatchTicket - 1u) / kBatchTicket);  // (the launcher refuses batches beyond 2^32 tickets)
+    uint32_t queue_shard = blockIdx.x % kQueueShards;  // (queue_take)
     bool drained = false;
     uint32_t n_rays = 0, n_hits = 0;  // wave-uniform (ballot counts)
 
@@ -106,15 +108,12 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             unsigned long long want = __ballot(T.st == ST_DONE && my_ray == kNone);
             while (want != 0ull && !drained) {
                 if (used >= kBatchTicket) {
-                    uint32_t t = 0;
-                    if (lane == 0)
-                        t = atomicAdd(B.ticket, 1u);
-                    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);  // (a scalar: the queue state stays in scalar registers)
-                    chunk = (unsigned long long)t * kBatchTicket;
-                    if (chunk >= B.n) {
+                    const uint32_t t = queue_take(B.ticket, tickets, queue_shard, lane);
+                    if (t == kQueueDry) {
                         drained = true;
                         break;
                     }
+                    chunk = (unsigned long long)t * kBatchTicket;
                     used = 0u;
                 }
                 const uint32_t avail = kBatchTicket - used;

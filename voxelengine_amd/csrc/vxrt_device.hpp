@@ -121,6 +121,61 @@ __host__ __device__ inline bool grid_is_wide(int cx, int cy, int cz)
     return cx > (int)kFieldCapXZ || cz > (int)kFieldCapXZ || cy > (int)kFieldCapY || cx + cy + cz + 4 >= kMaxSteps;
 }
 
+// ---- the work queue of the persistent kernels ------------------------------------------------------------------------
+// A queue of `total` tickets handed out by atomic counters.  ONE counter serves about 80 M atomics a second whatever the
+// launch does between them (same-address atomics execute one after the other at the memory side; measured:
+// profiles/r04_work_queue.md) -- 16 views of 1080p primary rays ask for more than twice that, and the bench workload
+// already for two thirds of it.  So the queue is cut into kQueueShards interleaved sub-queues, each with a counter on a
+// line of its own: shard q holds the tickets q, q + S, q + 2 S, ... (every shard runs through the launch's hand-out order
+// at the same pace), a wave draws from shard (workgroup number mod S) -- with S = 8 the waves of one XCD share one counter
+// -- and, when that one is dry, looks at all the counters with one load and moves on to the next shard that still has
+// tickets.  Tickets stay single tiles: nothing gets coarser at the tail of a launch (chunks of 2-8 tickets per atomic,
+// fixed or guided by what is left, with and without shards: the batched launches gain as much, single-view launches lose
+// 5-30 %; same note).
+#ifndef VXRT_QUEUE_SHARDS
+#define VXRT_QUEUE_SHARDS 8
+#endif
+#ifndef VXRT_QUEUE_STRIDE
+#define VXRT_QUEUE_STRIDE 128  // words between two shards' counters
+#endif
+constexpr uint32_t kQueueShards = VXRT_QUEUE_SHARDS, kQueueStride = VXRT_QUEUE_STRIDE;
+constexpr uint32_t kQueueWords = kQueueShards * kQueueStride;  // one launch's queue head (zeroed per launch)
+constexpr uint32_t kQueueDry = 0xFFFFFFFFu;
+static_assert(kQueueShards >= 1 && kQueueShards <= 32 && (kQueueShards & (kQueueShards - 1)) == 0, "shards: a power of two up to 32");
+
+// tickets of shard `shard` in a queue of `total`
+__host__ __device__ inline uint32_t queue_holds(uint32_t shard, uint32_t total)
+{
+    return total > shard ? (total - shard + kQueueShards - 1u) / kQueueShards : 0u;
+}
+
+#ifndef VXRT_HOST_CHECK
+// The next ticket of the queue, or kQueueDry.  Called by the whole (converged) wave; `shard` is the wave's current shard
+// (wave-uniform, kept by the caller; start: workgroup number mod kQueueShards).  Every wave leaves through `open == 0`:
+// a counter only grows, a shard found dry stays dry, and the loop moves on only to a shard whose counter was below its end.
+__device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t total, uint32_t& shard, uint32_t lane)
+{
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0)
+            t = atomicAdd(&heads[shard * kQueueStride], 1u);
+        // (readfirstlane: the ticket is a scalar, so the queue state stays in scalar registers and its branches are scalar)
+        const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * kQueueShards + shard;
+        if (ticket < total)
+            return ticket;
+        if (kQueueShards == 1u)
+            return kQueueDry;
+        // this shard is dry: which ones are not?  Lane k looks at shard k.
+        const uint32_t mine = lane < kQueueShards ? lane : 0u;
+        const uint32_t head = __hip_atomic_load(&heads[mine * kQueueStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t open = (uint32_t)__ballot(lane < kQueueShards && head < queue_holds(mine, total));
+        if (open == 0u)
+            return kQueueDry;
+        const uint32_t above = shard + 1u < 32u ? open >> (shard + 1u) : 0u;  // the next open shard, cyclically
+        shard = above != 0u ? shard + 1u + (uint32_t)__builtin_ctz(above) : (uint32_t)__builtin_ctz(open);
+    }
+}
+#endif
 
 struct RayCounters {
     uint32_t coarse_probes, brick_entries, fine_probes;

@@ -448,7 +448,7 @@ hipError_t launch_render(const RenderArgs& A, bool stats, int variant, hipStream
     const unsigned long long ntiles =
         (unsigned long long)((A.width + 7u) / 8u) * ((A.launch_rows + 7u) / 8u) * (A.nviews ? A.nviews : 1u);
     const unsigned waves = render_grid_waves(A, ntiles);
-    const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int), stream);
+    const hipError_t e = hipMemsetAsync(A.tile_counter, 0, sizeof(unsigned int) * kQueueWords, stream);
     if (e != hipSuccess)  // a kernel started on a queue head that was not reset would skip or repeat tiles
         return e;
     const bool second_bounce = A.bounce_depth >= 2 && A.bounce_samples > 0;
@@ -492,7 +492,8 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
     // persistent wavefronts pulling tickets of consecutive rays, for batches of at least 8 rays per lane of the persistent
     // grid (below that the queue cannot balance much, and short rays are cheaper one per lane)
     const unsigned resident = B.persistent_waves / 4u * (unsigned)VXRT_BATCH_OCC;
-    const bool persistent = B.ticket && resident && B.n >= 8ull * 64ull * resident;
+    const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
+    const bool persistent = B.ticket && resident && B.n >= 8ull * 64ull * resident && tickets < (unsigned long long)kQueueDry;
     if (!persistent) {
         if (stats && B.W.c_wide)
             hipLaunchKernelGGL((k_trace_batch_wave2<true, true>), grid, block, 0, stream, B);
@@ -504,10 +505,9 @@ hipError_t launch_trace_batch(const BatchArgs& B, bool stats, int variant, hipSt
             hipLaunchKernelGGL((k_trace_batch_wave2<false, false>), grid, block, 0, stream, B);
         return hipSuccess;
     }
-    const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int), stream);
+    const hipError_t e = hipMemsetAsync(B.ticket, 0, sizeof(unsigned int) * kQueueWords, stream);
     if (e != hipSuccess)
         return e;
-    const unsigned long long tickets = (B.n + kBatchTicket - 1) / kBatchTicket;
     const dim3 g((unsigned)(tickets < resident ? tickets : resident)), b(64);
     if (stats && B.W.c_wide)
         hipLaunchKernelGGL((k_trace_batch_persist<true, true>), g, b, 0, stream, B);

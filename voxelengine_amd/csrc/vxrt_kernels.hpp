@@ -52,7 +52,7 @@ struct RenderArgs {
     float* color_aov;
     long long* hit_aov;
     unsigned long long* stats;
-    unsigned int* tile_counter;  // persistent kernel: next 8x8 tile of the launch grid to hand out (zeroed per launch)
+    unsigned int* tile_counter;  // persistent kernel: the queue head of the launch's 8x8 tiles (kQueueWords words, zeroed per launch; queue_take)
     unsigned int persistent_waves;
     const unsigned int* tile_order;  // optional permutation of the launch grid's 8x8 tiles (hand-out order), or NULL
     // default hand-out order, tile-row granular: the k-th tile row handed out is row_order[k] (row_order_n = number
@@ -97,7 +97,7 @@ struct BatchArgs {
     uint8_t* hit;
     long long* voxel;
     unsigned long long* stats;
-    unsigned int* ticket;     // persistent batch kernel: next 64-ray ticket of the queue (zeroed per launch), or NULL
+    unsigned int* ticket;     // persistent batch kernel: the queue head of the 64-ray tickets (kQueueWords words, zeroed per launch), or NULL
     unsigned int persistent_waves;
     int max_steps;            // Raytrace's maxSteps (VolumeRaytracer.cu:354,386); kMaxSteps unless the caller lowered it
 };

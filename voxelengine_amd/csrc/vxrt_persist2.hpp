@@ -237,6 +237,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
     // (measured: 2x slower frames at 8 pixels per ticket), and handing out only the last tiles in smaller pieces
     // did not shorten the frame either.
     uint32_t tile = 0, tile_used = 64u, tile_view = 0;
+    uint32_t queue_shard = blockIdx.x % kQueueShards;  // (queue_take)
     bool drained = false;
     unsigned long long dg_iters = 0, dg_walk = 0, dg_drain = 0;  // STATS only: loop diagnostics
     unsigned int dg_runs[3] = {0, 0, 0}, dg_lanes[3] = {0, 0, 0};  // next / end / box phase executions, lanes served
@@ -496,14 +497,8 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             unsigned long long want = __ballot(T.st == ST_DONE && stage == PX_NONE);
             while (want != 0ull && !drained) {
                 if (tile_used >= 64u) {
-                    uint32_t t = 0;
-                    if (lane == 0)
-                        t = atomicAdd(A.tile_counter, 1u);
-                    // (readfirstlane: the ticket is a scalar, so the queue state -- tile, tile_used, drained -- stays in scalar
-                    // registers and its branches are scalar branches; as a lane shuffle the compiler kept `drained` as a lane mask
-                    // that it re-merged with exec on every trip of the wave loop)
-                    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                    if (tile >= ntiles * (MULTI ? A.nviews : 1u)) {
+                    tile = queue_take(A.tile_counter, ntiles * (MULTI ? A.nviews : 1u), queue_shard, lane);
+                    if (tile == kQueueDry) {
                         drained = true;
                         break;
                     }

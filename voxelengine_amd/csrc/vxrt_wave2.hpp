@@ -125,12 +125,16 @@ __device__ __forceinline__ float vmin(float a, float b) { float r; asm("v_min_f3
 __device__ __forceinline__ float vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// A value computed HERE, on every lane that is active here: keeps the compiler from sinking a few cheap instructions into an
+// exec-mask branch of their own (four scalar instructions and a branch to skip two vector ones)
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }
 #else
 // (host build: IEEE minNum / maxNum as the instructions are -- a NaN operand loses)
 __device__ __forceinline__ float vmin(float a, float b) { return fminf(a, b); }
 __device__ __forceinline__ float vmax(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ float vmin3(float a, float b, float c) { return vmin(vmin(a, b), c); }
 __device__ __forceinline__ float vmax3(float a, float b, float c) { return vmax(vmax(a, b), c); }
+__device__ __forceinline__ void pin(float&) {}
 #endif
 
 // bit (index mod 32) of a word: v_bfe_u32 takes the offset from the low five bits of its operand, so the index needs no mask
@@ -426,8 +430,10 @@ struct WaveTracerT {
         int bx, by, bz;
         cells_of(W, fine, before, bx, by, bz);
         const bool on_x = dec == kRemDecX, on_y = dec == kRemDecY, on_z = dec == kRemDecZ;
-        return mk3(on_x ? (float)(bx + (d.x > 0 ? 1 : 0)) : ws.x + (t * d.x), on_y ? (float)(by + (d.y > 0 ? 1 : 0)) : ws.y + (t * d.y),
-                   on_z ? (float)(bz + (d.z > 0 ? 1 : 0)) : ws.z + (t * d.z));
+        float face_x = (float)(bx + (d.x > 0 ? 1 : 0)), face_y = (float)(by + (d.y > 0 ? 1 : 0)), face_z = (float)(bz + (d.z > 0 ? 1 : 0));
+        float lin_x = ws.x + (t * d.x), lin_y = ws.y + (t * d.y), lin_z = ws.z + (t * d.z);
+        pin(face_x), pin(face_y), pin(face_z), pin(lin_x), pin(lin_y), pin(lin_z);  // (both arms, then a select)
+        return mk3(on_x ? face_x : lin_x, on_y ? face_y : lin_y, on_z ? face_z : lin_z);
     }
 
     // A lane goes back to its walk after a phase (a suspected step that passed its checks, a tight box that was missed).
@@ -489,8 +495,12 @@ struct WaveTracerT {
             const f3 cr = mk3(dec_last == kRemDecX ? (float)(bx + (d.x > 0 ? 1 : 0)) : lin.x,
                               dec_last == kRemDecY ? (float)(by + (d.y > 0 ? 1 : 0)) : lin.y,
                               dec_last == kRemDecZ ? (float)(bz + (d.z > 0 ? 1 : 0)) : lin.z);
-            const bool region_fail = is_fine && stepped &&
-                                     (cr.x < 0.0f || cr.x > F || cr.y < 0.0f || cr.y > F || cr.z < 0.0f || cr.z > F);
+            // (a component outside [0, F] on either side; min3 / max3 pass over a NaN component as the comparisons do)
+            float cr_lo = vmin3(cr.x, cr.y, cr.z), cr_hi = vmax3(cr.x, cr.y, cr.z);
+            float lin_lo = vmin3(lin.x, lin.y, lin.z), lin_hi = vmax3(lin.x, lin.y, lin.z);
+            f3 pc_prev = cross_of(W, is_fine, rpp, dec_prev, tp);  // the crossing point of the step before, if the last one does not count
+            pin(cr_lo), pin(cr_hi), pin(lin_lo), pin(lin_hi);
+            const bool region_fail = is_fine & stepped & ((cr_lo < 0.0f) | (cr_hi > F));
             const bool resume = !hit && !exiting && !region_fail && !exhausted;  // a step that was only suspected: walk on
             if (resume) {
                 if (WIDE) {
@@ -511,7 +521,7 @@ struct WaveTracerT {
                     rpp = virt ? armed + dec_last + dec_prev : rpp;
                     rem0 = virt ? so_far + px + py + pz : rem0;
                 }
-                const bool lin_inside = !(lin.x < 0.0f || lin.x > F || lin.y < 0.0f || lin.y > F || lin.z < 0.0f || lin.z > F);
+                const bool lin_inside = !((lin_lo < 0.0f) | (lin_hi > F));
                 walk_on(W, is_fine, lin_inside);
                 st = ST_WALK;
             } else {
@@ -526,9 +536,7 @@ struct WaveTracerT {
                     cnt.fine_probes += is_fine ? probed : 0u;
                     cnt.coarse_probes += is_fine ? 0u : probed;
                 }
-                f3 pc = cr;
-                if (!last_counts)
-                    pc = cross_of(W, is_fine, rpp, dec_prev, tp);
+                const f3 pc = mk3(last_counts ? cr.x : pc_prev.x, last_counts ? cr.y : pc_prev.y, last_counts ? cr.z : pc_prev.z);
                 point.x = steps != 0u ? pc.x : ws.x;
                 point.y = steps != 0u ? pc.y : ws.y;
                 point.z = steps != 0u ? pc.z : ws.z;
