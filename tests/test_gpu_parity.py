@@ -500,6 +500,28 @@ def test_tile_hand_out_order_never_changes_the_frame(eng, vxo):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("W,H", [(8, 8), (20, 8), (72, 40), (264, 136), (1000, 24)])
+def test_tile_queue_hands_out_every_tile_once(eng, vxo, W, H):
+    """The tile queue is cut into interleaved shards with a counter each (queue_take): frames with fewer tiles than shards,
+    with tile counts that are no multiple of a shard round, and launches of several such views must trace every pixel
+    exactly once -- the ray counter equals the pixel count -- and equal the oracle."""
+    vx, ctx, torch = eng
+    w = vxo.World.generate(vxo.GEN_INT_TERRAIN, 128, 128, 128, 16)
+    _upload(ctx, w)
+    pos, f, u, r = helpers.camera("A", w.dims, vxo)
+    p = vxo.make_params(W, H, pos, f, u, r, frame_number=1)
+    want = w.render(p, fb=np.zeros((H, W, 4), np.uint8))["fb"]
+    ctx.frame_stats()
+    for nviews in (1, 3, 16):
+        views = [dict(fb=torch.full((H, W, 4), 9, dtype=torch.uint8, device="cuda"), origin=pos, fwd=f, up=u, right=r, frame_number=1)
+                 for _ in range(nviews)]
+        ctx.RenderViews(W, H, views, vx.RenderOptions())
+        assert ctx.kernel_for_launch(W, H, vx.RenderOptions(), nviews=nviews) == 7
+        assert ctx.frame_stats().primary_rays == W * H * nviews
+        for v in views:
+            assert np.array_equal(v["fb"].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("variant", [4, 1])
 def test_multi_view_launch_equals_single_view_launches(eng, vxo, variant):
     """vxrt_render_views: several views in one launch (the queue runs on from one view's tiles into the next's).

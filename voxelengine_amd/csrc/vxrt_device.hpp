@@ -143,36 +143,49 @@ constexpr uint32_t kQueueWords = kQueueShards * kQueueStride;  // one launch's q
 constexpr uint32_t kQueueDry = 0xFFFFFFFFu;
 static_assert(kQueueShards >= 1 && kQueueShards <= 32 && (kQueueShards & (kQueueShards - 1)) == 0, "shards: a power of two up to 32");
 
-// tickets of shard `shard` in a queue of `total`
-__host__ __device__ inline uint32_t queue_holds(uint32_t shard, uint32_t total)
+// Shard `shard` holds the tickets whose group of `granule` consecutive tickets has a number == shard (mod S).
+__host__ __device__ inline uint32_t queue_ticket(uint32_t shard, uint32_t local, uint32_t granule)
 {
-    return total > shard ? (total - shard + kQueueShards - 1u) / kQueueShards : 0u;
+    return ((local / granule) * kQueueShards + shard) * granule + local % granule;
+}
+// tickets of shard `shard` in a queue of `total`
+__host__ __device__ inline uint32_t queue_holds(uint32_t shard, uint32_t total, uint32_t granule)
+{
+    const uint32_t round = granule * kQueueShards, full = total / round, rest = total - full * round;
+    const uint32_t part = rest > shard * granule ? rest - shard * granule : 0u;
+    return full * granule + (part < granule ? part : granule);
+}
+
+// the next shard with tickets after `shard`, cyclically (`open`: bit k = shard k still has tickets; not zero)
+__host__ __device__ inline uint32_t queue_next_shard(uint32_t open, uint32_t shard)
+{
+    const uint32_t above = shard + 1u < 32u ? open >> (shard + 1u) : 0u;
+    return above != 0u ? shard + 1u + (uint32_t)__builtin_ctz(above) : (uint32_t)__builtin_ctz(open);
 }
 
 #ifndef VXRT_HOST_CHECK
 // The next ticket of the queue, or kQueueDry.  Called by the whole (converged) wave; `shard` is the wave's current shard
 // (wave-uniform, kept by the caller; start: workgroup number mod kQueueShards).  Every wave leaves through `open == 0`:
 // a counter only grows, a shard found dry stays dry, and the loop moves on only to a shard whose counter was below its end.
-__device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t total, uint32_t& shard, uint32_t lane)
+__device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t total, uint32_t granule, uint32_t& shard, uint32_t lane)
 {
     for (;;) {
         uint32_t t = 0;
         if (lane == 0)
             t = atomicAdd(&heads[shard * kQueueStride], 1u);
         // (readfirstlane: the ticket is a scalar, so the queue state stays in scalar registers and its branches are scalar)
-        const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * kQueueShards + shard;
-        if (ticket < total)
-            return ticket;
+        const uint32_t local = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (local < queue_holds(shard, total, granule))
+            return queue_ticket(shard, local, granule);
         if (kQueueShards == 1u)
             return kQueueDry;
         // this shard is dry: which ones are not?  Lane k looks at shard k.
         const uint32_t mine = lane < kQueueShards ? lane : 0u;
         const uint32_t head = __hip_atomic_load(&heads[mine * kQueueStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t open = (uint32_t)__ballot(lane < kQueueShards && head < queue_holds(mine, total));
+        const uint32_t open = (uint32_t)__ballot(lane < kQueueShards && head < queue_holds(mine, total, granule));
         if (open == 0u)
             return kQueueDry;
-        const uint32_t above = shard + 1u < 32u ? open >> (shard + 1u) : 0u;  // the next open shard, cyclically
-        shard = above != 0u ? shard + 1u + (uint32_t)__builtin_ctz(above) : (uint32_t)__builtin_ctz(open);
+        shard = queue_next_shard(open, shard);
     }
 }
 #endif

@@ -161,6 +161,9 @@ __device__ __forceinline__ const RenderArgs& kernarg_reload(const RenderArgs& in
 // end-of-walk waits until its lanes are as many as the others (N = 1), ray-finished and the tight-box phase (which now
 // also enters the brick) until they are half as many.  Sweep in profiles/r03_variant7.md.
 // probe pairs per loop iteration (between two rounds of votes)
+#ifndef VXRT_QUEUE_GRANULE
+#define VXRT_QUEUE_GRANULE 4u  // consecutive tiles of the hand-out order that belong to the same shard of the queue
+#endif
 #ifndef VXRT_SUBROUNDS2
 #define VXRT_SUBROUNDS2 3
 #endif
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
             unsigned long long want = __ballot(T.st == ST_DONE && stage == PX_NONE);
             while (want != 0ull && !drained) {
                 if (tile_used >= 64u) {
-                    tile = queue_take(A.tile_counter, ntiles * (MULTI ? A.nviews : 1u), queue_shard, lane);
+                    tile = queue_take(A.tile_counter, ntiles * (MULTI ? A.nviews : 1u), VXRT_QUEUE_GRANULE, queue_shard, lane);
                     if (tile == kQueueDry) {
                         drained = true;
                         break;
