@@ -285,7 +285,7 @@ int vxrt_create(int device, vxrt_ctx** out)
     c->device = device;
     // counters, and a ring of queue heads for the persistent kernels: launches on different streams may be in flight
     // together (frame k+1 fills the SIMD slots frame k's last waves leave), each needs its own queue head
-    const size_t stat_words = vxrt::kStatCount;
+    const size_t stat_words = (size_t)vxrt::kStatRows * vxrt::kStatRowStride;  // (vxrt_kernels.hpp: rows of counters)
     hipError_t e = hipMalloc((void**)&c->d_stats, stat_words * sizeof(unsigned long long));
     if (e == hipSuccess)
         e = hipMemset(c->d_stats, 0, stat_words * sizeof(unsigned long long));
@@ -817,8 +817,12 @@ int vxrt_frame_stats_get(vxrt_ctx* c, vxrt_frame_stats* out)
         return fail(VXRT_ERR_INVALID, "NULL argument");
     VX_HIP(hipSetDevice(c->device));
     VX_HIP(hipDeviceSynchronize());  // every stream of the device, non-blocking ones included
-    unsigned long long now[vxrt::kStatCount], h[vxrt::kStatCount];
-    VX_HIP(hipMemcpy(now, c->d_stats, sizeof(now), hipMemcpyDeviceToHost));
+    unsigned long long now[vxrt::kStatCount] = {}, h[vxrt::kStatCount];
+    std::vector<unsigned long long> rows((size_t)vxrt::kStatRows * vxrt::kStatRowStride);
+    VX_HIP(hipMemcpy(rows.data(), c->d_stats, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (unsigned r = 0; r < vxrt::kStatRows; ++r)
+        for (int i = 0; i < vxrt::kStatCount; ++i)
+            now[i] += rows[(size_t)r * vxrt::kStatRowStride + i];
     for (int i = 0; i < vxrt::kStatCount; ++i) {  // what was added since the previous read; the device copy only grows
         h[i] = now[i] - c->stats_base[i];
         c->stats_base[i] = now[i];

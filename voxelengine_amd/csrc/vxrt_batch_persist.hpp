@@ -166,13 +166,14 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
         const unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries),
                                  p2 = wave_sum(T.cnt.fine_probes), g0 = wave_sum(T.cnt.slack_loads), g1 = wave_sum(T.cnt.stray_loads);
         if (lane == 0) {
-            atomicAdd(&B.stats[kStatGuardSlack], g0);
-            atomicAdd(&B.stats[kStatGuardStray], g1);
-            atomicAdd(&B.stats[kStatPrimary], (unsigned long long)n_rays);
-            atomicAdd(&B.stats[kStatPrimaryHits], (unsigned long long)n_hits);
-            atomicAdd(&B.stats[kStatCoarseProbes], p0);
-            atomicAdd(&B.stats[kStatBrickEntries], p1);
-            atomicAdd(&B.stats[kStatFineProbes], p2);
+            unsigned long long* const stats = stats_row_of<kStatRows, kStatRowStride>(B.stats, blockIdx.x);
+            atomicAdd(&stats[kStatGuardSlack], g0);
+            atomicAdd(&stats[kStatGuardStray], g1);
+            atomicAdd(&stats[kStatPrimary], (unsigned long long)n_rays);
+            atomicAdd(&stats[kStatPrimaryHits], (unsigned long long)n_hits);
+            atomicAdd(&stats[kStatCoarseProbes], p0);
+            atomicAdd(&stats[kStatBrickEntries], p1);
+            atomicAdd(&stats[kStatFineProbes], p2);
         }
     }
 }

@@ -164,6 +164,13 @@ __host__ __device__ inline uint32_t queue_next_shard(uint32_t open, uint32_t sha
 }
 
 #ifndef VXRT_HOST_CHECK
+// this workgroup's row of the statistics counters (vxrt_kernels.hpp: kStatRows rows of kStatRowStride words)
+template <unsigned ROWS, unsigned STRIDE>
+__device__ __forceinline__ unsigned long long* stats_row_of(unsigned long long* stats, unsigned workgroup)
+{
+    return stats + (size_t)(workgroup % ROWS) * STRIDE;
+}
+
 // The next ticket of the queue, or kQueueDry.  Called by the whole (converged) wave; `shard` is the wave's current shard
 // (wave-uniform, kept by the caller; start: workgroup number mod kQueueShards).  Every wave leaves through `open == 0`:
 // a counter only grows, a shard found dry stays dry, and the loop moves on only to a shard whose counter was below its end.

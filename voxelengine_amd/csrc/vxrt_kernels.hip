@@ -246,19 +246,20 @@ __global__ __launch_bounds__(256) void k_render(RenderArgs A)
     // one set of atomics per wavefront
     unsigned long long s0 = wave_sum(n_primary), s1 = wave_sum(n_shadow), s2 = wave_sum(n_bounce),
                        s3 = wave_sum(n_hits);
-    if (lane == 0 && A.stats) {
-        atomicAdd(&A.stats[kStatPrimary], s0);
-        atomicAdd(&A.stats[kStatShadow], s1);
-        atomicAdd(&A.stats[kStatBounce], s2);
-        atomicAdd(&A.stats[kStatPrimaryHits], s3);
+    unsigned long long* const stats = A.stats ? stats_row_of<kStatRows, kStatRowStride>(A.stats, blockIdx.x + blockIdx.y * gridDim.x) : nullptr;
+    if (lane == 0 && stats) {
+        atomicAdd(&stats[kStatPrimary], s0);
+        atomicAdd(&stats[kStatShadow], s1);
+        atomicAdd(&stats[kStatBounce], s2);
+        atomicAdd(&stats[kStatPrimaryHits], s3);
     }
     if (STATS) {
         unsigned long long p0 = wave_sum(cnt.coarse_probes), p1 = wave_sum(cnt.brick_entries),
                            p2 = wave_sum(cnt.fine_probes);
-        if (lane == 0 && A.stats) {
-            atomicAdd(&A.stats[kStatCoarseProbes], p0);
-            atomicAdd(&A.stats[kStatBrickEntries], p1);
-            atomicAdd(&A.stats[kStatFineProbes], p2);
+        if (lane == 0 && stats) {
+            atomicAdd(&stats[kStatCoarseProbes], p0);
+            atomicAdd(&stats[kStatBrickEntries], p1);
+            atomicAdd(&stats[kStatFineProbes], p2);
         }
     }
 }
@@ -303,11 +304,12 @@ __global__ __launch_bounds__(256) void k_trace_batch(BatchArgs B)
         unsigned long long r = wave_sum(rays), h = wave_sum(hits), p0 = wave_sum(cnt.coarse_probes),
                            p1 = wave_sum(cnt.brick_entries), p2 = wave_sum(cnt.fine_probes);
         if (lane == 0) {
-            atomicAdd(&B.stats[kStatPrimary], r);
-            atomicAdd(&B.stats[kStatPrimaryHits], h);
-            atomicAdd(&B.stats[kStatCoarseProbes], p0);
-            atomicAdd(&B.stats[kStatBrickEntries], p1);
-            atomicAdd(&B.stats[kStatFineProbes], p2);
+            unsigned long long* const stats = stats_row_of<kStatRows, kStatRowStride>(B.stats, blockIdx.x);
+            atomicAdd(&stats[kStatPrimary], r);
+            atomicAdd(&stats[kStatPrimaryHits], h);
+            atomicAdd(&stats[kStatCoarseProbes], p0);
+            atomicAdd(&stats[kStatBrickEntries], p1);
+            atomicAdd(&stats[kStatFineProbes], p2);
         }
     }
 }
@@ -380,13 +382,14 @@ __global__ __launch_bounds__(256) void k_trace_batch_wave2(BatchArgs B)
                                  p1 = wave_sum(cnt.brick_entries), p2 = wave_sum(cnt.fine_probes), g0 = wave_sum(cnt.slack_loads),
                                  g1 = wave_sum(cnt.stray_loads);
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(&B.stats[kStatGuardSlack], g0);
-            atomicAdd(&B.stats[kStatGuardStray], g1);
-            atomicAdd(&B.stats[kStatPrimary], r);
-            atomicAdd(&B.stats[kStatPrimaryHits], h);
-            atomicAdd(&B.stats[kStatCoarseProbes], p0);
-            atomicAdd(&B.stats[kStatBrickEntries], p1);
-            atomicAdd(&B.stats[kStatFineProbes], p2);
+            unsigned long long* const stats = stats_row_of<kStatRows, kStatRowStride>(B.stats, blockIdx.x);
+            atomicAdd(&stats[kStatGuardSlack], g0);
+            atomicAdd(&stats[kStatGuardStray], g1);
+            atomicAdd(&stats[kStatPrimary], r);
+            atomicAdd(&stats[kStatPrimaryHits], h);
+            atomicAdd(&stats[kStatCoarseProbes], p0);
+            atomicAdd(&stats[kStatBrickEntries], p1);
+            atomicAdd(&stats[kStatFineProbes], p2);
         }
     }
 }

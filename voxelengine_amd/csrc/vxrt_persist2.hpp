@@ -592,33 +592,34 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         n_hits = C[3];
     }
     const unsigned long long s0 = n_primary, s1 = n_shadow, s2 = n_bounce, s3 = n_hits;
-    if (lane == 0 && A_kern.stats) {
-        atomicAdd(&A_kern.stats[kStatPrimary], s0);
-        atomicAdd(&A_kern.stats[kStatShadow], s1);
-        atomicAdd(&A_kern.stats[kStatBounce], s2);
-        atomicAdd(&A_kern.stats[kStatPrimaryHits], s3);
+    unsigned long long* const stats = A_kern.stats ? stats_row_of<kStatRows, kStatRowStride>(A_kern.stats, blockIdx.x) : nullptr;
+    if (lane == 0 && stats) {
+        atomicAdd(&stats[kStatPrimary], s0);
+        atomicAdd(&stats[kStatShadow], s1);
+        atomicAdd(&stats[kStatBounce], s2);
+        atomicAdd(&stats[kStatPrimaryHits], s3);
     }
     if (STATS) {
         const unsigned long long p0 = wave_sum(T.cnt.coarse_probes), p1 = wave_sum(T.cnt.brick_entries), p2 = wave_sum(T.cnt.fine_probes);
         const unsigned long long g0 = wave_sum(T.cnt.slack_loads), g1 = wave_sum(T.cnt.stray_loads);
-        if (lane == 0 && A_kern.stats) {
-            atomicAdd(&A_kern.stats[kStatCoarseProbes], p0);
-            atomicAdd(&A_kern.stats[kStatBrickEntries], p1);
-            atomicAdd(&A_kern.stats[kStatFineProbes], p2);
-            atomicAdd(&A_kern.stats[kStatGuardSlack], g0);
-            atomicAdd(&A_kern.stats[kStatGuardStray], g1);
-            atomicAdd(&A_kern.stats[kStatDbgIters], dg_iters);
-            atomicAdd(&A_kern.stats[kStatDbgWalkLanes], dg_walk);
-            atomicAdd(&A_kern.stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);
-            atomicAdd(&A_kern.stats[kStatDbgEndRuns], (unsigned long long)dg_runs[1]);
-            atomicAdd(&A_kern.stats[kStatDbgBoxRuns], (unsigned long long)dg_runs[2]);
-            atomicAdd(&A_kern.stats[kStatDbgNextLanes], (unsigned long long)dg_lanes[0]);
-            atomicAdd(&A_kern.stats[kStatDbgEndLanes], (unsigned long long)dg_lanes[1]);
-            atomicAdd(&A_kern.stats[kStatDbgBoxLanes], (unsigned long long)dg_lanes[2]);
-            atomicAdd(&A_kern.stats[kStatDbgLifetime], wall_clock64() - dg_t0);
-            atomicAdd(&A_kern.stats[kStatDbgDrained], dg_drain);
-            atomicAdd(&A_kern.stats[kStatDbgNextTicks], dg_next_ticks);
-            atomicAdd(&A_kern.stats[kStatDbgParkTicks], dg_park_ticks);
+        if (lane == 0 && stats) {
+            atomicAdd(&stats[kStatCoarseProbes], p0);
+            atomicAdd(&stats[kStatBrickEntries], p1);
+            atomicAdd(&stats[kStatFineProbes], p2);
+            atomicAdd(&stats[kStatGuardSlack], g0);
+            atomicAdd(&stats[kStatGuardStray], g1);
+            atomicAdd(&stats[kStatDbgIters], dg_iters);
+            atomicAdd(&stats[kStatDbgWalkLanes], dg_walk);
+            atomicAdd(&stats[kStatDbgNextRuns], (unsigned long long)dg_runs[0]);
+            atomicAdd(&stats[kStatDbgEndRuns], (unsigned long long)dg_runs[1]);
+            atomicAdd(&stats[kStatDbgBoxRuns], (unsigned long long)dg_runs[2]);
+            atomicAdd(&stats[kStatDbgNextLanes], (unsigned long long)dg_lanes[0]);
+            atomicAdd(&stats[kStatDbgEndLanes], (unsigned long long)dg_lanes[1]);
+            atomicAdd(&stats[kStatDbgBoxLanes], (unsigned long long)dg_lanes[2]);
+            atomicAdd(&stats[kStatDbgLifetime], wall_clock64() - dg_t0);
+            atomicAdd(&stats[kStatDbgDrained], dg_drain);
+            atomicAdd(&stats[kStatDbgNextTicks], dg_next_ticks);
+            atomicAdd(&stats[kStatDbgParkTicks], dg_park_ticks);
         }
     }
 }
