@@ -108,7 +108,7 @@ __global__ __launch_bounds__(64, VXRT_BATCH_OCC) void k_trace_batch_persist(Batc
             unsigned long long want = __ballot(T.st == ST_DONE && my_ray == kNone);
             while (want != 0ull && !drained) {
                 if (used >= kBatchTicket) {
-                    const uint32_t t = queue_take(B.ticket, tickets, 1u, queue_shard, lane);
+                    const uint32_t t = queue_take(B.ticket, tickets, queue_shard, lane);
                     if (t == kQueueDry) {
                         drained = true;
                         break;

@@ -174,6 +174,8 @@ __device__ __forceinline__ unsigned long long* stats_row_of(unsigned long long* 
 // The next ticket of the queue, or kQueueDry.  Called by the whole (converged) wave; `shard` is the wave's current shard
 // (wave-uniform, kept by the caller; start: workgroup number mod kQueueShards).  Every wave leaves through `open == 0`:
 // a counter only grows, a shard found dry stays dry, and the loop moves on only to a shard whose counter was below its end.
+// (The ticket is tested against the queue's end directly: queue_ticket grows with `local`, so that is `local <
+// queue_holds(shard)`.)
 __device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t total, uint32_t granule, uint32_t& shard, uint32_t lane)
 {
     for (;;) {
@@ -182,8 +184,9 @@ __device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t tot
             t = atomicAdd(&heads[shard * kQueueStride], 1u);
         // (readfirstlane: the ticket is a scalar, so the queue state stays in scalar registers and its branches are scalar)
         const uint32_t local = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (local < queue_holds(shard, total, granule))
-            return queue_ticket(shard, local, granule);
+        const uint32_t ticket = ((local / granule) * kQueueShards + shard) * granule + local % granule;
+        if (ticket < total)
+            return ticket;
         if (kQueueShards == 1u)
             return kQueueDry;
         // this shard is dry: which ones are not?  Lane k looks at shard k.
@@ -192,7 +195,33 @@ __device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t tot
         const uint32_t open = (uint32_t)__ballot(lane < kQueueShards && head < queue_holds(mine, total, granule));
         if (open == 0u)
             return kQueueDry;
-        shard = queue_next_shard(open, shard);
+        const uint32_t above = shard + 1u < 32u ? open >> (shard + 1u) : 0u;  // the next open shard, cyclically (queue_next_shard)
+        shard = above != 0u ? shard + 1u + (uint32_t)__builtin_ctz(above) : (uint32_t)__builtin_ctz(open);
+    }
+}
+
+// The same for a queue of single tickets per shard round (granule 1: the batch queue), written out.  (Not a matter of taste:
+// k_trace_batch_persist calling the function above with granule = 1 compiles to all but the same instructions and runs the
+// 4 M incoherent rays of tools/batch_probe.py 14 % slower -- 1.71 against 1.97-1.99 Grays/s, four sessions; unexplained,
+// profiles/r04_work_queue.md section 7.)
+__device__ __forceinline__ uint32_t queue_take(unsigned int* heads, uint32_t total, uint32_t& shard, uint32_t lane)
+{
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0)
+            t = atomicAdd(&heads[shard * kQueueStride], 1u);
+        const uint32_t ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)t) * kQueueShards + shard;
+        if (ticket < total)
+            return ticket;
+        if (kQueueShards == 1u)
+            return kQueueDry;
+        const uint32_t mine = lane < kQueueShards ? lane : 0u;
+        const uint32_t head = __hip_atomic_load(&heads[mine * kQueueStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t open = (uint32_t)__ballot(lane < kQueueShards && head < (total > mine ? (total - mine + kQueueShards - 1u) / kQueueShards : 0u));
+        if (open == 0u)
+            return kQueueDry;
+        const uint32_t above = shard + 1u < 32u ? open >> (shard + 1u) : 0u;
+        shard = above != 0u ? shard + 1u + (uint32_t)__builtin_ctz(above) : (uint32_t)__builtin_ctz(open);
     }
 }
 #endif

@@ -34,7 +34,10 @@ enum StatSlot {
 // The counters are kStatRows rows of kStatRowStride words; a kernel adds to row (workgroup mod kStatRows) -- stats_row -- and
 // vxrt_frame_stats_get sums the rows.  (One row: the four ray counters every wave of a 16-view launch adds when it leaves
 // were 20 000 atomics on four addresses, ~12 ns each and one after the other: 1.7 % of the launch, profiles/r04_work_queue.md.)
-constexpr unsigned kStatRows = 64, kStatRowStride = 32;
+#ifndef VXRT_STAT_ROWS
+#define VXRT_STAT_ROWS 64
+#endif
+constexpr unsigned kStatRows = VXRT_STAT_ROWS, kStatRowStride = 32;
 static_assert(kStatCount <= (int)kStatRowStride, "a row holds every counter");
 
 constexpr unsigned kMaxScheduledTileRows = 512;  // frames up to 4096 launch rows get a tile schedule
