@@ -54,8 +54,10 @@ def test_gather_pipeline_over_a_one_rank_nccl_group(vxo):
             ctx.deinterleave_views(W, H, plan.strip_rows, world, sh, step_bytes, plan.shard_bytes, V, fr, W * H * 4)
             seen.append(fr.clone())
 
-        pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames, deinterleave,
-                                       nbytes=step_bytes)
+        # as bench.py does for N > 1: consecutive steps on two render streams, frame k de-interleaved into buffer k mod 2
+        frames2 = [frames, torch.zeros_like(frames)]
+        pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames2, deinterleave,
+                                       nbytes=step_bytes, streams=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
         cams = ["A", "B", "D", "C"]
 
         def views_of(step, target):
@@ -68,11 +70,12 @@ def test_gather_pipeline_over_a_one_rank_nccl_group(vxo):
             return out
 
         opts = dict(shadow=True, bounce_samples=1)
-        nsteps = 3   # more steps than pipeline slots: both buffer pairs are reused
+        nsteps = 5   # more steps than pipeline slots: both buffer pairs are reused, on both streams
         for k in range(nsteps):
-            ctx.RenderViews(W, H, views_of(k, pipe.local(k)),
-                            vx.RenderOptions(strip_rows=plan.strip_rows, strip_count=world, strip_index=0, compact=True, **opts))
-            pipe.submit(k)
+            with pipe.stream(k):
+                ctx.RenderViews(W, H, views_of(k, pipe.local(k)),
+                                vx.RenderOptions(strip_rows=plan.strip_rows, strip_count=world, strip_index=0, compact=True, **opts))
+                pipe.submit(k)
         pipe.flush()
         torch.cuda.synchronize()
         assert len(seen) == nsteps

@@ -49,3 +49,26 @@ for count in (1, 2, 4, 8):
         rays = ctx.frame_stats().total_rays()
         print("%s shard 1/%d, %d view(s) per launch: %.3f ms per frame, %.0f Mrays/s" % (
             name, count, nv, 1e3 * dt / (reps * nv), rays / dt / 1e6), flush=True)
+        if nv == 16:  # the same launches alternating between two streams: step k+1 fills the SIMD slots step k's tail leaves
+            ext = [torch.cuda.Stream(), torch.cuda.Stream()]
+            bufs2 = [[torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(nv)] for _ in range(2)]
+
+            def launch2(k):
+                views = [dict(fb=bufs2[k & 1][j], origin=cams[(k * nv + j) % 4][1], fwd=cams[(k * nv + j) % 4][0][0],
+                              up=cams[(k * nv + j) % 4][0][1], right=cams[(k * nv + j) % 4][0][2], frame_number=k * nv + j + 1)
+                         for j in range(nv)]
+                ctx.RenderViews(W, H, views, o, stream=ext[k & 1].cuda_stream)
+
+            reps2 = 8
+            for k in range(2):
+                launch2(k)
+            torch.cuda.synchronize()
+            ctx.frame_stats()
+            t0 = time.perf_counter()
+            for k in range(reps2):
+                launch2(k)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            rays = ctx.frame_stats().total_rays()
+            print("%s shard 1/%d, %d view(s) per launch, two launches in flight: %.3f ms per frame, %.0f Mrays/s" % (
+                name, count, nv, 1e3 * dt / (reps2 * nv), rays / dt / 1e6), flush=True)

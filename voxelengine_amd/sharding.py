@@ -62,11 +62,20 @@ class GatherPipeline:
     inside ``submit(k)``; ``pipe.flush()`` completes the last frame.  Each rank owns two packed shard buffers,
     the root two gather buffers, so a buffer is reused only after the collective that read it has completed
     (``work.wait()`` orders the stream, it does not block the host for NCCL).
+
+    Two render streams (``with pipe.stream(k): ...`` around the three calls of frame k, device tensors only): frame k's
+    render, the wait for the gather that last read its buffer, the issue of its own gather and the de-interleave of frame
+    k-1 all sit on stream k mod 2, so the render of frame k+1 waits for nothing of frame k and fills the SIMD slots its
+    last waves leave -- a strip shard is a small launch whose tail is a fifth of it (tools/views_probe.py: 1/8 shards of
+    16 views 6.7 -> 7.9 Grays/s per GPU).  ``frame_on_root`` may then be a pair of buffers (frame k lands in buffer
+    k mod 2): two de-interleaves on two streams must not write one buffer.
     """
 
-    def __init__(self, plan: ShardPlan, make_buffer, frame_on_root, deinterleave, group=None, nbytes: int | None = None):
+    def __init__(self, plan: ShardPlan, make_buffer, frame_on_root, deinterleave, group=None, nbytes: int | None = None,
+                 streams=None):
         """``nbytes``: bytes each rank contributes per step (default one packed shard; several views per launch
-        contribute several shards back to back -- one larger collective instead of several small ones)."""
+        contribute several shards back to back -- one larger collective instead of several small ones).
+        ``streams``: None, or two ``torch.cuda.Stream`` objects (see above)."""
         self.plan, self.frame, self.deinterleave, self.group = plan, frame_on_root, deinterleave, group
         nbytes = plan.shard_bytes if nbytes is None else int(nbytes)
         self.locals = [make_buffer(nbytes) for _ in range(2)]
@@ -74,6 +83,22 @@ class GatherPipeline:
                        for _ in range(2)] if plan.rank == 0 else [None, None]
         self.works = [None, None]
         self.pending = None  # frame index gathered but not yet de-interleaved on the root
+        self.streams = streams
+        self.read = [None, None]  # with streams: events behind the de-interleave that read the root's gather buffer b
+        if streams is not None:
+            assert len(streams) == 2
+
+    def stream(self, k: int):
+        """Context manager: the stream frame k's work is issued on (a no-op without render streams)."""
+        if self.streams is None:
+            import contextlib
+            return contextlib.nullcontext()
+        import torch
+        return torch.cuda.stream(self.streams[k & 1])
+
+    def frame_of(self, k: int):
+        """The root's buffer frame k is (or will be) de-interleaved into."""
+        return self.frame[k & 1] if isinstance(self.frame, (list, tuple)) else self.frame
 
     def local(self, k: int):
         b = k & 1
@@ -87,6 +112,10 @@ class GatherPipeline:
 
         b = k & 1
         p = self.plan
+        if self.read[b] is not None:  # frame k-2's de-interleave ran on the other stream: this gather overwrites what it read
+            import torch
+            torch.cuda.current_stream().wait_event(self.read[b])
+            self.read[b] = None
         if p.rank == 0:
             self.works[b] = dist.gather(self.locals[b], [self.shards[b][r] for r in range(p.world_size)], dst=0,
                                         group=self.group, async_op=True)
@@ -103,12 +132,17 @@ class GatherPipeline:
             self.works[b].wait()
             self.works[b] = None
         if self.plan.rank == 0:
-            self.deinterleave(self.shards[b], self.frame)
+            self.deinterleave(self.shards[b], self.frame_of(k))
+            if self.streams is not None:
+                import torch
+                self.read[b] = torch.cuda.Event()
+                self.read[b].record()
         self.pending = None
 
     def flush(self):
         if self.pending is not None:
-            self._finish(self.pending)
+            with self.stream(self.pending):
+                self._finish(self.pending)
         for b in range(2):
             if self.works[b] is not None:
                 self.works[b].wait()
