@@ -329,6 +329,25 @@ def run(args):
             s2 = ctx.frame_stats()
             assert s2.total_rays() == rays_local, "ray counts differ between multi-view and two-in-flight launches"
 
+    # ... and the bench step itself (V views per launch) with two steps in flight on two streams: what the N > 1 path does on
+    # every rank, measured here on whole frames (an extra field; `value` stays one step at a time, so that the HIP events
+    # around a launch time that launch alone)
+    dt3 = None
+    if V > 1 and world == 1 and not args.force_gather:
+        ext3 = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        tgt3 = [frames, torch.zeros_like(frames)]
+        for k in range(2):  # warm both streams
+            ctx.RenderViews(W, H, views_of(args.warmup + k, tgt3[k & 1]), opts(), stream=ext3[k & 1].cuda_stream)
+        torch.cuda.synchronize()
+        ctx.frame_stats()
+        t3 = time.perf_counter()
+        for k in range(args.steps):
+            ctx.RenderViews(W, H, views_of(args.warmup + k, tgt3[k & 1]), opts(), stream=ext3[k & 1].cuda_stream)
+        torch.cuda.synchronize()
+        dt3 = time.perf_counter() - t3
+        s3 = ctx.frame_stats()
+        assert s3.total_rays() == rays_local, "ray counts differ between one step at a time and two steps in flight"
+
     # SURVEY 8(d)'s side measurements, rank 0 of a one-GPU run only (untimed region): a measured stream-copy ceiling beside the
     # spec peak -- a device-to-device copy of 1 GiB, bytes read + bytes written per second -- and the per-camera split of the
     # workload from single-view launches (cameras A-D differ several-fold in rays per pixel chain)
@@ -488,6 +507,12 @@ def run(args):
                 "roofline_frac": round(bytes_total / dt2 / 1e9 / HBM_PEAK_GBS, 5),
                 "note": "same frames, one vxrt_render launch per frame on two alternating streams, the host at most two frames "
                         "ahead: the call pattern of the facade's RenderScreenAsync/WaitFrame for interactive callers"}
+        if dt3 is not None:
+            result["two_steps_in_flight"] = {
+                "value": round(rays_total / dt3 / 1e6, 2), "unit": "Mrays/s", "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                "roofline_frac": round(bytes_total / dt3 / 1e9 / HBM_PEAK_GBS, 5),
+                "note": "the same steps alternating between two streams (the next launch's first waves fill the SIMD slots the "
+                        "previous launch's tail leaves): what every rank of an N > 1 run does; not `value`"}
         if world > 1:
             # per-rank roofline of the dominant kernel: algorithmic bytes of the rank's launches / its launch time
             result["roofline"]["per_rank"] = [
