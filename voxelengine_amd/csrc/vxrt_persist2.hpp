@@ -285,8 +285,12 @@ __global__ __launch_bounds__(64, VXRT_PERSIST2_OCC) void k_render_persist2(Rende
         } else {
             sink.put(pc.x, pc.y, shaded);  // the ray direction, Renderer.cu:254-258
         }
-        if (pc.tx == (A.width >> 1) && pc.ty == (A.height >> 1))  // crosshair on launch coordinates, :261-268
-            sink.put(pc.x, pc.y, mk3(10, 10, 10));
+        if (pc.tx == (A.width >> 1) && pc.ty == (A.height >> 1)) {  // crosshair on launch coordinates, :261-268
+            float ten = 10.0f;
+            pin(ten);  // (materialised here: the compiler hoisted the constant vector to the top of the kernel and SPILLED it --
+                       // the kernel's only scratch use)
+            sink.put(pc.x, pc.y, mk3(ten, ten, ten));
+        }
         if (A.mode == 1 && pc.x < (Wd >> 1) && pc.y > (Hd >> 1))  // :270-275
             sink.put(pc.x, pc.y, mk3((float)p_steps / 256.0f, 0, 0));
     };
