@@ -66,19 +66,24 @@ def _pipeline_worker(rank, world, port, W, H, rows, out_path):
         _reference_deinterleave(plan)(shards, fr)
         seen.append(fr.clone())
 
-    pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8), frame, deint)
+    # frame k lands in buffer k mod 2 (what bench.py passes for N > 1, where two render streams alternate); on the CPU the
+    # stream context of a step is a no-op
+    pair = [frame, torch.zeros_like(frame)] if rank == 0 else [None, None]
+    pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8), pair, deint)
     frames = []
     for k in range(5):
         g = torch.Generator().manual_seed(100 + k)
         full = torch.randint(0, 256, (H, W, 4), dtype=torch.uint8, generator=g)
         frames.append(full)
-        buf = pipe.local(k).view(plan.max_rows, W, 4)
-        for lr in range(plan.local_rows):
-            buf[lr] = full[plan.frame_row(rank, lr)]
-        pipe.submit(k)
+        with pipe.stream(k):
+            buf = pipe.local(k).view(plan.max_rows, W, 4)
+            for lr in range(plan.local_rows):
+                buf[lr] = full[plan.frame_row(rank, lr)]
+            pipe.submit(k)
     pipe.flush()
     if rank == 0:
         ok = len(seen) == 5 and all(torch.equal(a, b) for a, b in zip(seen, frames))
+        ok = ok and torch.equal(pipe.frame_of(4), frames[4]) and torch.equal(pipe.frame_of(3), frames[3]) and pipe.frame_of(4) is pair[0]
         torch.save(dict(ok=bool(ok)), out_path)
     dist.barrier()
     dist.destroy_process_group()
