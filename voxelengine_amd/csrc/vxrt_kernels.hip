@@ -416,7 +416,11 @@ int resolve_render_variant(const RenderArgs& A, int variant)
 // Measured on one MI355X (profiles/r04_grid_policy.md): 1080p primary rays only (32 400 tiles), one view per launch:
 // 5120 / 3840 / 2560 / 1920 / 1280 / 960 waves = 2830 / 3111 / 3481 / 3654 / 3352 / 2948 Mrays/s; 1080p primary + shadow +
 // bounce (97 200 weighted tiles): 5120 / 3840 / 2560 waves = 4626 / 4567 / 4098; 16 views per launch: the full grid.
-constexpr unsigned kTilesPerWave = 17u;
+// That sweep was taken while every wave's tickets and leaving atomics queued on single addresses, which penalised waves as
+// such (17 tiles per wave then); with the sharded queue and the counter rows (profiles/r04_work_queue.md section 8) the 1080p
+// primary-only frame runs 6276 / 6500 / 6284 / 5673-5686 / 4745 Mrays/s at 6 / 9 / 12 / 17 / 24 tiles per wave, the shaded
+// one 5945-6029 at anything up to 17 (its grid is the full one from 19 down) and 5815 / 5215 at 24 / 34.
+constexpr unsigned kTilesPerWave = 10u;
 static unsigned render_grid_waves(const RenderArgs& A, unsigned long long ntiles)
 {
     const unsigned resident = std::max(1u, A.persistent_waves / 4u * (unsigned)VXRT_PERSIST2_OCC);
