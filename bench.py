@@ -204,7 +204,7 @@ def run(args):
     if sharded and not rehearse:
         frames2 = [frames, torch.zeros_like(frames)] if rank == 0 else [None, None]
         pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames2, deinterleave,
-                                       nbytes=step_bytes, streams=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
+                                       nbytes=step_bytes, streams=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], depth=3)
 
     def step(i, ev=None, one_view_launches=False):
         if pipe:

@@ -57,7 +57,7 @@ def test_gather_pipeline_over_a_one_rank_nccl_group(vxo):
         # as bench.py does for N > 1: consecutive steps on two render streams, frame k de-interleaved into buffer k mod 2
         frames2 = [frames, torch.zeros_like(frames)]
         pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8, device=dev), frames2, deinterleave,
-                                       nbytes=step_bytes, streams=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)])
+                                       nbytes=step_bytes, streams=[torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)], depth=3)
         cams = ["A", "B", "D", "C"]
 
         def views_of(step, target):
@@ -70,7 +70,7 @@ def test_gather_pipeline_over_a_one_rank_nccl_group(vxo):
             return out
 
         opts = dict(shadow=True, bounce_samples=1)
-        nsteps = 5   # more steps than pipeline slots: both buffer pairs are reused, on both streams
+        nsteps = 7   # more steps than pipeline slots: all three buffers are reused, on both streams
         for k in range(nsteps):
             with pipe.stream(k):
                 ctx.RenderViews(W, H, views_of(k, pipe.local(k)),

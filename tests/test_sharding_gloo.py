@@ -104,9 +104,10 @@ def _multi_view_pipeline_worker(rank, world, port, W, H, rows, views, out_path):
             _reference_deinterleave(plan)(shards[:, j * sb:(j + 1) * sb].contiguous(), fr[j])
         seen.append(fr.clone())
 
-    pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8), frames_out, deint, nbytes=views * sb)
+    # three buffers deep, as bench.py runs it for N > 1 (7 steps: every buffer is reused at least twice)
+    pipe = sharding.GatherPipeline(plan, lambda n: torch.zeros(n, dtype=torch.uint8), frames_out, deint, nbytes=views * sb, depth=3)
     steps = []
-    for k in range(4):
+    for k in range(7):
         g = torch.Generator().manual_seed(500 + k)
         full = torch.randint(0, 256, (views, H, W, 4), dtype=torch.uint8, generator=g)
         steps.append(full)
@@ -119,7 +120,7 @@ def _multi_view_pipeline_worker(rank, world, port, W, H, rows, views, out_path):
         pipe.submit(k)
     pipe.flush()
     if rank == 0:
-        ok = len(seen) == 4 and all(torch.equal(a, b) for a, b in zip(seen, steps))
+        ok = len(seen) == 7 and all(torch.equal(a, b) for a, b in zip(seen, steps))
         torch.save(dict(ok=bool(ok)), out_path)
     dist.barrier()
     dist.destroy_process_group()

@@ -56,11 +56,11 @@ class ShardPlan:
 
 
 class GatherPipeline:
-    """Two-deep pipeline of frames: the gather of frame k runs (on RCCL's stream) while frame k+1 is rendered.
+    """Pipeline of frames: the gather of frame k runs (on RCCL's stream) while the next frames are rendered.
 
     Per frame: ``buf = pipe.local(k)`` -> render into it -> ``pipe.submit(k)``.  The root de-interleaves frame k-1
-    inside ``submit(k)``; ``pipe.flush()`` completes the last frame.  Each rank owns two packed shard buffers,
-    the root two gather buffers, so a buffer is reused only after the collective that read it has completed
+    inside ``submit(k)``; ``pipe.flush()`` completes the last frame.  Each rank owns ``depth`` packed shard buffers,
+    the root ``depth`` gather buffers, so a buffer is reused only after the collective that read it has completed
     (``work.wait()`` orders the stream, it does not block the host for NCCL).
 
     Two render streams (``with pipe.stream(k): ...`` around the three calls of frame k, device tensors only): frame k's
@@ -68,23 +68,28 @@ class GatherPipeline:
     k-1 all sit on stream k mod 2, so the render of frame k+1 waits for nothing of frame k and fills the SIMD slots its
     last waves leave -- a strip shard is a small launch whose tail is a fifth of it (tools/views_probe.py: 1/8 shards of
     16 views 6.7 -> 7.9 Grays/s per GPU).  ``frame_on_root`` may then be a pair of buffers (frame k lands in buffer
-    k mod 2): two de-interleaves on two streams must not write one buffer.
+    k mod 2): two de-interleaves on two streams must not write one buffer.  With streams, ``depth`` should be 3: the
+    persistent render kernel leaves RCCL's kernel no room on the GPU until its waves start to leave, so the gather of
+    frame k runs in the tail of frame k+1 -- exactly when frame k+2 should start, which with two buffers would have to
+    wait for that gather.
     """
 
     def __init__(self, plan: ShardPlan, make_buffer, frame_on_root, deinterleave, group=None, nbytes: int | None = None,
-                 streams=None):
+                 streams=None, depth: int = 2):
         """``nbytes``: bytes each rank contributes per step (default one packed shard; several views per launch
         contribute several shards back to back -- one larger collective instead of several small ones).
-        ``streams``: None, or two ``torch.cuda.Stream`` objects (see above)."""
+        ``streams``: None, or two ``torch.cuda.Stream`` objects (see above).  ``depth``: buffers per rank (>= 2)."""
         self.plan, self.frame, self.deinterleave, self.group = plan, frame_on_root, deinterleave, group
         nbytes = plan.shard_bytes if nbytes is None else int(nbytes)
-        self.locals = [make_buffer(nbytes) for _ in range(2)]
+        assert depth >= 2
+        self.depth = int(depth)
+        self.locals = [make_buffer(nbytes) for _ in range(self.depth)]
         self.shards = [make_buffer(plan.world_size * nbytes).view(plan.world_size, nbytes)
-                       for _ in range(2)] if plan.rank == 0 else [None, None]
-        self.works = [None, None]
+                       for _ in range(self.depth)] if plan.rank == 0 else [None] * self.depth
+        self.works = [None] * self.depth
         self.pending = None  # frame index gathered but not yet de-interleaved on the root
         self.streams = streams
-        self.read = [None, None]  # with streams: events behind the de-interleave that read the root's gather buffer b
+        self.read = [None] * self.depth  # with streams: events behind the de-interleave that read the root's gather buffer b
         if streams is not None:
             assert len(streams) == 2
 
@@ -101,8 +106,8 @@ class GatherPipeline:
         return self.frame[k & 1] if isinstance(self.frame, (list, tuple)) else self.frame
 
     def local(self, k: int):
-        b = k & 1
-        if self.works[b] is not None:  # the gather issued two frames ago read this buffer
+        b = k % self.depth
+        if self.works[b] is not None:  # the gather issued `depth` frames ago read this buffer
             self.works[b].wait()
             self.works[b] = None
         return self.locals[b]
@@ -110,9 +115,9 @@ class GatherPipeline:
     def submit(self, k: int):
         import torch.distributed as dist
 
-        b = k & 1
+        b = k % self.depth
         p = self.plan
-        if self.read[b] is not None:  # frame k-2's de-interleave ran on the other stream: this gather overwrites what it read
+        if self.read[b] is not None:  # frame k-depth's de-interleave may have run on the other stream: this gather overwrites what it read
             import torch
             torch.cuda.current_stream().wait_event(self.read[b])
             self.read[b] = None
@@ -127,7 +132,7 @@ class GatherPipeline:
     def _finish(self, k: int):
         if self.pending is None or self.pending != k:
             return
-        b = k & 1
+        b = k % self.depth
         if self.works[b] is not None:
             self.works[b].wait()
             self.works[b] = None
@@ -143,7 +148,7 @@ class GatherPipeline:
         if self.pending is not None:
             with self.stream(self.pending):
                 self._finish(self.pending)
-        for b in range(2):
+        for b in range(self.depth):
             if self.works[b] is not None:
                 self.works[b].wait()
                 self.works[b] = None
